@@ -1,0 +1,128 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes wrapper of oracle/liboracle.so, the CPU restatement of the reference hot path.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+nothing under pbrt-rs_amd/ does.  Parity status: pinned by the reference's own known-answer
+tests where they exist (tests/test_oracle_golden.py); BVH traversal, patch intersection,
+interval arithmetic and the RNG/hash stream have no reference test => "parity unpinned"
+ — the reference is Rust and cannot be built in this image.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+RAY_DTYPE = np.dtype([("o", "<f4", 3), ("tmax", "<f4"), ("d", "<f4", 3), ("time", "<f4")])
+HIT_DTYPE = np.dtype([("prim_id", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+
+SPLIT_SAH, SPLIT_MIDDLE, SPLIT_EQUAL_COUNTS = 1, 2, 3
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        f, i, u32, u64, p = C.c_float, C.c_int, C.c_uint32, C.c_uint64, C.c_void_p
+        sig = {
+            "ora_scene_create": (p, []), "ora_scene_destroy": (None, [p]),
+            "ora_add_sphere": (u32, [p, f, f, f, f, p, p, i]),
+            "ora_add_patch_mesh": (u32, [p, p, u32, p, u32, i, i]),
+            "ora_add_triangle_mesh": (u32, [p, p, u32, p, u32]),
+            "ora_build": (i, [p, i, i]), "ora_scene_bounds": (None, [p, p]),
+            "ora_trace_closest": (None, [p, p, u64, p, p, i, i]),
+            "ora_trace_any": (None, [p, p, u64, p, p, i]),
+            "ora_wide_trace": (None, [p, p, p, u64, p, i, p, i]),
+            "ora_next_float_up": (f, [f]), "ora_next_float_down": (f, [f]), "ora_gamma": (f, [i]),
+            "ora_exponent": (i, [f]), "ora_fast_exp": (f, [f]), "ora_gaussian": (f, [f, f, f]),
+            "ora_erf_inv": (f, [f]), "ora_evaluate_polynomial": (f, [f, p, i]),
+            "ora_difference_of_products": (f, [f, f, f, f]), "ora_solve_quadratic": (i, [f, f, f, p]),
+            "ora_mat4_inverse": (i, [p, p]), "ora_xf_bounds": (None, [p, p, p]),
+            "ora_visible_wavelengths_pdf": (f, [f]), "ora_sample_visible_wavelengths": (f, [f]),
+            "ora_sphere_basic_intersect": (i, [f, f, f, f, p, p, p, p, f, p]),
+            "ora_intersect_patch": (i, [p, p, f, p, p]),
+            "ora_hash_pixel": (u64, [C.c_int32, C.c_int32, u32]),
+            "ora_sampler_stream": (None, [C.c_int32, C.c_int32, u32, u64, u64, i, p]),
+            "ora_pcg32_next": (u32, [p]), "ora_pcg32_new": (None, [u64, u64, p]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Scene:
+    """Vec<Arc<PrimitiveEnum>> + BVHAggregate of the reference, on the CPU."""
+
+    def __init__(self):
+        self._l = lib()
+        self._h = C.c_void_p(self._l.ora_scene_create())
+
+    def add_sphere(self, radius, z_min, z_max, phi_max_deg, rfo, ofr, reverse=False):
+        a, b = _f32(rfo).reshape(16), _f32(ofr).reshape(16)
+        return self._l.ora_add_sphere(self._h, radius, z_min, z_max, phi_max_deg, a.ctypes.data, b.ctypes.data, int(reverse))
+
+    def add_patch_mesh(self, positions, indices, reverse=False, swaps=False):
+        pos = _f32(positions).reshape(-1, 3)
+        idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 4)
+        return self._l.ora_add_patch_mesh(self._h, pos.ctypes.data, len(pos), idx.ctypes.data, len(idx), int(reverse), int(swaps))
+
+    def add_triangle_mesh(self, positions, indices):
+        pos = _f32(positions).reshape(-1, 3)
+        idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+        return self._l.ora_add_triangle_mesh(self._h, pos.ctypes.data, len(pos), idx.ctypes.data, len(idx))
+
+    def build(self, method=SPLIT_MIDDLE, max_prims_in_node=255):
+        return self._l.ora_build(self._h, method, max_prims_in_node)
+
+    def bounds(self):
+        out = np.zeros(6, np.float32)
+        self._l.ora_scene_bounds(self._h, out.ctypes.data)
+        return out[:3], out[3:]
+
+    def intersect(self, rays, nthreads=8, brute_force=False):
+        assert rays.dtype == RAY_DTYPE
+        out = np.empty(len(rays), HIT_DTYPE)
+        ctr = np.zeros(2, np.uint64)
+        self._l.ora_trace_closest(self._h, rays.ctypes.data, len(rays), out.ctypes.data, ctr.ctypes.data, nthreads, int(brute_force))
+        return out, {"nodes_visited": int(ctr[0]), "prims_tested": int(ctr[1])}
+
+    def intersect_p(self, rays, nthreads=8):
+        assert rays.dtype == RAY_DTYPE
+        out = np.empty(len(rays), np.uint8)
+        ctr = np.zeros(2, np.uint64)
+        self._l.ora_trace_any(self._h, rays.ctypes.data, len(rays), out.ctypes.data, ctr.ctypes.data, nthreads)
+        return out, {"nodes_visited": int(ctr[0]), "prims_tested": int(ctr[1])}
+
+    def __del__(self):
+        try:
+            self._l.ora_scene_destroy(self._h)
+        except Exception:
+            pass
+
+
+def wide_trace(node_buf, prim_buf, rays, any_hit=False, nthreads=8):
+    """Walk the GPU-layout tree on the CPU; returns (hits or occlusion, counters)."""
+    assert rays.dtype == RAY_DTYPE
+    out = np.empty(len(rays), np.uint8 if any_hit else HIT_DTYPE)
+    ctr = np.zeros(2, np.uint64)
+    lib().ora_wide_trace(node_buf.ctypes.data, prim_buf.ctypes.data, rays.ctypes.data, len(rays), out.ctypes.data,
+                         int(any_hit), ctr.ctypes.data, nthreads)
+    return out, {"nodes_visited": int(ctr[0]), "prims_tested": int(ctr[1])}

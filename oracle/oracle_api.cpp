@@ -1,0 +1,215 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see ref_core.h header).
+// extern "C" surface of the CPU oracle, loaded with ctypes by tests/, smoke()
+// and bench.py's cpu_baseline leg.  Nothing under pbrt-rs_amd/ may use it.
+#include <atomic>
+#include <thread>
+
+#include "ref_render.h"
+#include "ref_scene.h"
+#include "wide_walk.h"
+
+using namespace ora;
+
+struct OraRay { float o[3]; float tmax; float d[3]; float time; };
+struct OraHit { uint32_t prim_id; float t, u, v; };
+
+struct OraScene {
+    Scene sc;
+    uint32_t next_id = 0;
+};
+
+static M4 m4_from(const float* p) {
+    M4 m;
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) m.m[r][c] = p[r * 4 + c];
+    return m;
+}
+
+template <class F>
+static void parallel_chunks(uint64_t n, int nthreads, F f) {
+    if (nthreads <= 1 || n < 4096) { f(0, n, 0); return; }
+    std::vector<std::thread> th;
+    std::atomic<uint64_t> next(0);
+    const uint64_t chunk = 4096;
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&, t]() {
+            for (;;) {
+                uint64_t b = next.fetch_add(chunk);
+                if (b >= n) break;
+                f(b, std::min(n, b + chunk), t);
+            }
+        });
+    for (auto& t : th) t.join();
+}
+
+static void fill_hit(const Scene& sc, const Hit& h, OraHit* o) {
+    o->prim_id = h.prim_id; o->t = h.t; o->u = h.u; o->v = h.v;
+    const Prim& p = sc.prims[h.prim_slot];
+    if (p.type == PRIM_SPHERE) {   // sphere.rs:382-385
+        const Sphere& s = sc.spheres[p.index];
+        o->u = h.phi / s.phi_max;
+        float theta = safe_acos(h.p_obj.z / s.radius);
+        o->v = (theta - s.theta_z_min) / (s.theta_z_max - s.theta_z_min);
+    }
+}
+
+extern "C" {
+
+OraScene* ora_scene_create() { return new OraScene(); }
+void ora_scene_destroy(OraScene* s) { delete s; }
+
+uint32_t ora_add_sphere(OraScene* s, float radius, float z_min, float z_max, float phi_max_deg,
+                        const float* rfo, const float* ofr, int reverse) {
+    s->sc.spheres.push_back(make_sphere(radius, z_min, z_max, phi_max_deg, m4_from(rfo), m4_from(ofr), reverse != 0));
+    Prim p{PRIM_SPHERE, (uint32_t)s->sc.spheres.size() - 1, s->next_id++};
+    s->sc.prims.push_back(p);
+    return p.id;
+}
+// positions are already in render space (BilinearPatchMesh::new transforms them, bilinear_patch.rs:649-655)
+uint32_t ora_add_patch_mesh(OraScene* s, const float* pos, uint32_t n_vert, const uint32_t* idx4, uint32_t n_patch,
+                            int reverse_orientation, int transform_swaps_handedness) {
+    (void)n_vert;
+    uint32_t first = s->next_id;
+    for (uint32_t i = 0; i < n_patch; ++i) {
+        Patch pt;
+        auto P = [&](uint32_t k) { return V3(pos[3 * k], pos[3 * k + 1], pos[3 * k + 2]); };
+        pt.p00 = P(idx4[4 * i]); pt.p10 = P(idx4[4 * i + 1]); pt.p01 = P(idx4[4 * i + 2]); pt.p11 = P(idx4[4 * i + 3]);
+        pt.flip_normal = (reverse_orientation != 0) ^ (transform_swaps_handedness != 0);
+        s->sc.patches.push_back(pt);
+        s->sc.prims.push_back(Prim{PRIM_PATCH, (uint32_t)s->sc.patches.size() - 1, s->next_id++});
+    }
+    return first;
+}
+// triangle (v0,v1,v2) == degenerate patch (v0,v1,v2,v2)
+uint32_t ora_add_triangle_mesh(OraScene* s, const float* pos, uint32_t n_vert, const uint32_t* idx3, uint32_t n_tri) {
+    (void)n_vert;
+    uint32_t first = s->next_id;
+    s->sc.patches.reserve(s->sc.patches.size() + n_tri);
+    s->sc.prims.reserve(s->sc.prims.size() + n_tri);
+    for (uint32_t i = 0; i < n_tri; ++i) {
+        Patch pt;
+        auto P = [&](uint32_t k) { return V3(pos[3 * k], pos[3 * k + 1], pos[3 * k + 2]); };
+        pt.p00 = P(idx3[3 * i]); pt.p10 = P(idx3[3 * i + 1]); pt.p01 = P(idx3[3 * i + 2]); pt.p11 = pt.p01;
+        pt.flip_normal = false;
+        s->sc.patches.push_back(pt);
+        s->sc.prims.push_back(Prim{PRIM_PATCH, (uint32_t)s->sc.patches.size() - 1, s->next_id++});
+    }
+    return first;
+}
+int ora_build(OraScene* s, int method, int max_prims_in_node) {
+    s->sc.build((SplitMethod)method, max_prims_in_node);
+    return (int)s->sc.nodes.size();
+}
+void ora_scene_bounds(OraScene* s, float* out6) {
+    B3 b = s->sc.bounds();
+    out6[0] = b.lo.x; out6[1] = b.lo.y; out6[2] = b.lo.z; out6[3] = b.hi.x; out6[4] = b.hi.y; out6[5] = b.hi.z;
+}
+// mode 0: reference BVH traversal; mode 1: brute force over all primitives
+void ora_trace_closest(OraScene* s, const OraRay* rays, uint64_t n, OraHit* out, uint64_t* counters2, int nthreads,
+                       int mode) {
+    std::vector<Counters> ctr(std::max(1, nthreads));
+    parallel_chunks(n, nthreads, [&](uint64_t b, uint64_t e, int tid) {
+        for (uint64_t i = b; i < e; ++i) {
+            const OraRay& r = rays[i];
+            Hit h;
+            V3 ro(r.o[0], r.o[1], r.o[2]), rd(r.d[0], r.d[1], r.d[2]);
+            bool ok = mode == 0 ? s->sc.intersect(ro, rd, r.tmax, &h, &ctr[tid]) : s->sc.brute_force(ro, rd, r.tmax, &h);
+            if (ok) fill_hit(s->sc, h, &out[i]);
+            else { out[i].prim_id = 0xFFFFFFFFu; out[i].t = r.tmax; out[i].u = 0; out[i].v = 0; }
+        }
+    });
+    if (counters2) {
+        counters2[0] = counters2[1] = 0;
+        for (auto& c : ctr) { counters2[0] += c.nodes_visited; counters2[1] += c.prims_tested; }
+    }
+}
+void ora_trace_any(OraScene* s, const OraRay* rays, uint64_t n, uint8_t* out, uint64_t* counters2, int nthreads) {
+    std::vector<Counters> ctr(std::max(1, nthreads));
+    parallel_chunks(n, nthreads, [&](uint64_t b, uint64_t e, int tid) {
+        for (uint64_t i = b; i < e; ++i) {
+            const OraRay& r = rays[i];
+            out[i] = s->sc.intersect_p(V3(r.o[0], r.o[1], r.o[2]), V3(r.d[0], r.d[1], r.d[2]), r.tmax, &ctr[tid]) ? 1 : 0;
+        }
+    });
+    if (counters2) {
+        counters2[0] = counters2[1] = 0;
+        for (auto& c : ctr) { counters2[0] += c.nodes_visited; counters2[1] += c.prims_tested; }
+    }
+}
+
+// Walk the GPU-layout wide BVH on the CPU (same order as the HIP kernel).  any_hit: out is uint8[n], else OraHit[n].
+void ora_wide_trace(const void* nodes, const void* prims, const OraRay* rays, uint64_t n, void* out, int any_hit,
+                    uint64_t* counters2, int nthreads) {
+    WideWalker ww{reinterpret_cast<const WNode*>(nodes), reinterpret_cast<const uint8_t*>(prims)};
+    std::vector<Counters> ctr(std::max(1, nthreads));
+    parallel_chunks(n, nthreads, [&](uint64_t b, uint64_t e, int tid) {
+        for (uint64_t i = b; i < e; ++i) {
+            const OraRay& r = rays[i];
+            uint32_t id; float t, u, v;
+            bool f = ww.walk(V3(r.o[0], r.o[1], r.o[2]), V3(r.d[0], r.d[1], r.d[2]), r.tmax, any_hit != 0, &id, &t, &u, &v, &ctr[tid]);
+            if (any_hit) reinterpret_cast<uint8_t*>(out)[i] = f ? 1 : 0;
+            else { OraHit& h = reinterpret_cast<OraHit*>(out)[i]; h.prim_id = id; h.t = t; h.u = u; h.v = v; }
+        }
+    });
+    if (counters2) {
+        counters2[0] = counters2[1] = 0;
+        for (auto& c : ctr) { counters2[0] += c.nodes_visited; counters2[1] += c.prims_tested; }
+    }
+}
+
+// ---- single-function probes used by the golden-vector tests -----------------------------------
+float ora_next_float_up(float v) { return next_float_up(v); }
+float ora_next_float_down(float v) { return next_float_down(v); }
+float ora_gamma(int n) { return gamma_n(n); }
+int ora_exponent(float v) { return exponent_f32(v); }
+float ora_fast_exp(float x) { return fast_exp(x); }
+float ora_gaussian(float x, float mu, float sigma) { return gaussian(x, mu, sigma); }
+float ora_erf_inv(float a) { return erf_inv(a); }
+float ora_evaluate_polynomial(float t, const float* c, int n) { return evaluate_polynomial(t, c, n); }
+float ora_difference_of_products(float a, float b, float c, float d) { return difference_of_products(a, b, c, d); }
+int ora_solve_quadratic(float a, float b, float c, float* t01) { return solve_quadratic(a, b, c, &t01[0], &t01[1]) ? 1 : 0; }
+int ora_mat4_inverse(const float* m16, float* out16) {
+    M4 r;
+    if (!m4_inverse(m4_from(m16), &r)) return 0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out16[i * 4 + j] = r.m[i][j];
+    return 1;
+}
+void ora_xf_bounds(const float* m16, const float* b6, float* out6) {
+    B3 b; b.lo = V3(b6[0], b6[1], b6[2]); b.hi = V3(b6[3], b6[4], b6[5]);
+    B3 r = xf_bounds(m4_from(m16), b);
+    out6[0] = r.lo.x; out6[1] = r.lo.y; out6[2] = r.lo.z; out6[3] = r.hi.x; out6[4] = r.hi.y; out6[5] = r.hi.z;
+}
+float ora_visible_wavelengths_pdf(float l) { return visible_wavelengths_pdf(l); }
+float ora_sample_visible_wavelengths(float u) { return sample_visible_wavelengths(u); }
+int ora_sphere_basic_intersect(float radius, float z_min, float z_max, float phi_max_deg, const float* rfo,
+                               const float* ofr, const float* o3, const float* d3, float t_max, float* out5) {
+    Sphere s = make_sphere(radius, z_min, z_max, phi_max_deg, m4_from(rfo), m4_from(ofr), false);
+    QuadricHit q;
+    if (!sphere_basic_intersect(s, V3(o3[0], o3[1], o3[2]), V3(d3[0], d3[1], d3[2]), t_max, &q)) return 0;
+    out5[0] = q.t_hit; out5[1] = q.p_obj.x; out5[2] = q.p_obj.y; out5[3] = q.p_obj.z; out5[4] = q.phi;
+    return 1;
+}
+int ora_intersect_patch(const float* o3, const float* d3, float t_max, const float* p12, float* tuv) {
+    PatchHit h;
+    auto P = [&](int k) { return V3(p12[3 * k], p12[3 * k + 1], p12[3 * k + 2]); };
+    if (!intersect_bilinear_patch(V3(o3[0], o3[1], o3[2]), V3(d3[0], d3[1], d3[2]), t_max, P(0), P(1), P(2), P(3), &h))
+        return 0;
+    tuv[0] = h.t; tuv[1] = h.u; tuv[2] = h.v;
+    return 1;
+}
+uint64_t ora_hash_pixel(int32_t x, int32_t y, uint32_t seed) { return hash_pixel(x, y, seed); }
+void ora_sampler_stream(int32_t x, int32_t y, uint32_t seed, uint64_t sample_index, uint64_t dim, int n, float* out) {
+    Pcg32 r = start_pixel_sample(x, y, seed, sample_index, dim);
+    for (int i = 0; i < n; ++i) out[i] = r.uniform_float();
+}
+uint32_t ora_pcg32_next(uint64_t* state_inc) {
+    Pcg32 r; r.state = state_inc[0]; r.inc = state_inc[1];
+    uint32_t v = r.next_u32();
+    state_inc[0] = r.state;
+    return v;
+}
+void ora_pcg32_new(uint64_t state, uint64_t stream, uint64_t* state_inc) {
+    Pcg32 r = Pcg32::create(state, stream);
+    state_inc[0] = r.state; state_inc[1] = r.inc;
+}
+
+}  // extern "C"

@@ -1,0 +1,355 @@
+// C ABI of libpbrt_mi355.so (include/pbrt_mi355.h): context, geometry upload, wide-BVH build,
+// batched closest-hit / any-hit kernels.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pbrt_mi355.h"
+#include "pm_build.h"
+#include "pm_device.hpp"
+
+#define TRACE_BLOCK 128
+
+struct pm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    pm::HostScene scene;
+    pm::Accel accel;
+    bool accel_valid = false;
+    int split_method = PM_SPLIT_SAH;
+    PmWideNode* d_nodes = nullptr;
+    uint4* d_prims = nullptr;
+    unsigned long long* d_counters = nullptr;   // rays, nodes, prims, overflow
+    bool counting = false;
+    uint64_t rays_counted = 0;
+    float last_ms = 0.0f;
+    // staging for host-pointer callers
+    void* d_stage_in = nullptr; size_t stage_in_cap = 0;
+    void* d_stage_out = nullptr; size_t stage_out_cap = 0;
+};
+
+static int fail(pm_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) return fail(c, PM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+static int ensure(pm_ctx* c, void** buf, size_t* cap, size_t need) {
+    if (*cap >= need) return PM_OK;
+    if (*buf) HIPCHK(c, hipFree(*buf));
+    *buf = nullptr; *cap = 0;
+    HIPCHK(c, hipMalloc(buf, need));
+    *cap = need;
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------------------------------ kernels
+// XCD-aware block remap: hardware deals consecutive workgroups round-robin over the 8 XCDs (each with
+// a private 4 MiB L2), so block b and b+8 share an L2.  Give every XCD one contiguous span of the ray
+// array, so rays that are neighbours in the (tile-ordered) input walk the same BVH region in one L2.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
+    const uint32_t q = nb >> 3, r = nb & 7u, x = b & 7u;
+    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (b >> 3);
+}
+
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const PmWideNode* __restrict__ nodes,
+                                                            const uint4* __restrict__ prims,
+                                                            const PmRay* __restrict__ rays, uint64_t n,
+                                                            PmHit* __restrict__ hits, uint8_t* __restrict__ occ,
+                                                            unsigned long long* __restrict__ counters) {
+    __shared__ uint2 stack[PM_LDS_STACK * TRACE_BLOCK];
+    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
+    const uint64_t i = (uint64_t)blk * TRACE_BLOCK + threadIdx.x;
+    pmd::TravCounters tc = {0u, 0u, 0u};
+    if (i < n) {
+        const float4* rp = reinterpret_cast<const float4*>(rays + i);
+        const float4 a = rp[0], b = rp[1];
+        pmd::Ray ray;
+        ray.o = pmd::mk3(a.x, a.y, a.z); ray.tmax = a.w; ray.d = pmd::mk3(b.x, b.y, b.z);
+        pmd::HitRec h;
+        const bool f = pmd::traverse<ANY, COUNT>(nodes, prims, ray, &h, stack + threadIdx.x, TRACE_BLOCK, &tc);
+        if (ANY) occ[i] = f ? 1 : 0;
+        else {
+            float4 o;
+            o.x = __uint_as_float(h.prim_id); o.y = h.t; o.z = h.u; o.w = h.v;
+            *reinterpret_cast<float4*>(hits + i) = o;
+        }
+    }
+    if (COUNT) {
+        // wave-level reduction, one atomic per wave per counter
+        unsigned long long nn = tc.nodes, pp = tc.prims;
+        for (int off = 32; off > 0; off >>= 1) { nn += __shfl_down(nn, off); pp += __shfl_down(pp, off); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&counters[1], nn); atomicAdd(&counters[2], pp); }
+    }
+    if (tc.overflow) atomicAdd(&counters[3], 1ull);
+}
+
+// ------------------------------------------------------------------------------------------ lifetime
+extern "C" int pm_create(int device_id, pm_ctx** out) {
+    if (!out) return PM_ERR_INVALID;
+    *out = nullptr;
+    if (device_id == -1) {   // host-only context: geometry + pm_build_accel + buffer export, no HIP call at all
+        pm_ctx* hc = new pm_ctx();
+        hc->device = -1;
+        *out = hc;
+        return PM_OK;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return PM_ERR_HIP;
+    pm_ctx* c = new pm_ctx();
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipMalloc(&c->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->d_counters, 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
+        delete c;
+        return PM_ERR_HIP;
+    }
+    *out = c;
+    return PM_OK;
+}
+extern "C" void pm_destroy(pm_ctx* c) {
+    if (!c) return;
+    if (c->device < 0) { delete c; return; }
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->d_nodes) (void)hipFree(c->d_nodes);
+    if (c->d_prims) (void)hipFree(c->d_prims);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_stage_in) (void)hipFree(c->d_stage_in);
+    if (c->d_stage_out) (void)hipFree(c->d_stage_out);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+extern "C" const char* pm_last_error(pm_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+// ------------------------------------------------------------------------------------------ geometry
+static pm::Box box_of_points(const float (*p)[3], int n) {
+    pm::Box b;
+    for (int k = 0; k < 3; ++k) { b.lo[k] = p[0][k]; b.hi[k] = p[0][k]; }
+    for (int i = 1; i < n; ++i)
+        for (int k = 0; k < 3; ++k) { b.lo[k] = std::fmin(b.lo[k], p[i][k]); b.hi[k] = std::fmax(b.hi[k], p[i][k]); }
+    return b;
+}
+static float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+extern "C" int pm_add_spheres(pm_ctx* c, const PmSphere* s, uint32_t n, uint32_t* first) {
+    if (!c || (!s && n)) return fail(c, PM_ERR_INVALID, "pm_add_spheres: null argument");
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* ofr = s[i].object_from_render;
+        const float* rfo = s[i].render_from_object;
+        if (!(ofr[12] == 0.f && ofr[13] == 0.f && ofr[14] == 0.f && ofr[15] == 1.f && rfo[12] == 0.f && rfo[13] == 0.f &&
+              rfo[14] == 0.f && rfo[15] == 1.f))
+            return fail(c, PM_ERR_UNSUPPORTED, "pm_add_spheres: only affine transforms (last row 0 0 0 1)");
+        if (!(s[i].radius > 0.f) || s[i].z_min > s[i].z_max)
+            return fail(c, PM_ERR_INVALID, "pm_add_spheres: radius must be > 0 and z_min <= z_max (sphere.rs:42-47)");
+    }
+    if (first) *first = c->scene.next_prim_id;
+    for (uint32_t i = 0; i < n; ++i) {
+        pm::HostSphere h;
+        // Sphere::new, shapes/sphere.rs:34-68
+        h.radius = s[i].radius;
+        h.z_min = clampf(s[i].z_min, -h.radius, h.radius);
+        h.z_max = clampf(s[i].z_max, -h.radius, h.radius);
+        h.phi_max = clampf(s[i].phi_max_deg, 0.0f, 360.0f) * (3.14159265358979323846f / 180.0f);
+        h.theta_z_min = std::acos(clampf(h.z_min / h.radius, -1.0f, 1.0f));
+        h.theta_z_max = std::acos(clampf(h.z_max / h.radius, -1.0f, 1.0f));
+        std::memcpy(h.render_from_object, s[i].render_from_object, 64);
+        std::memcpy(h.object_from_render, s[i].object_from_render, 64);
+        h.reverse_orientation = s[i].reverse_orientation != 0;
+        h.prim_id = c->scene.next_prim_id++;
+        // Sphere::bounds (sphere.rs:72-78) through Transform * Bounds3f (core/transform.rs:532-566)
+        const float* m = h.render_from_object;
+        const float blo[3] = {-h.radius, -h.radius, h.z_min}, bhi[3] = {h.radius, h.radius, h.z_max};
+        for (int r = 0; r < 3; ++r) {
+            float lo = m[r * 4 + 3], hi = m[r * 4 + 3];
+            for (int k = 0; k < 3; ++k) {
+                float a = m[r * 4 + k] * blo[k], b = m[r * 4 + k] * bhi[k];
+                lo += std::fmin(a, b); hi += std::fmax(a, b);
+            }
+            h.bounds.lo[r] = lo; h.bounds.hi[r] = hi;
+        }
+        c->scene.spheres.push_back(h);
+    }
+    c->accel_valid = false;
+    return PM_OK;
+}
+
+extern "C" int pm_add_patch_mesh(pm_ctx* c, const float* pos, uint32_t n_vert, const uint32_t* idx4, uint32_t n_patch,
+                                 const float* normals, int reverse_orientation, int swaps, uint32_t* first) {
+    if (!c || !pos || (!idx4 && n_patch)) return fail(c, PM_ERR_INVALID, "pm_add_patch_mesh: null argument");
+    if (normals) return fail(c, PM_ERR_UNSUPPORTED, "pm_add_patch_mesh: vertex normals not supported yet");
+    for (uint64_t i = 0; i < (uint64_t)n_patch * 4; ++i)
+        if (idx4[i] >= n_vert) return fail(c, PM_ERR_INVALID, "pm_add_patch_mesh: vertex index out of range");
+    if (first) *first = c->scene.next_prim_id;
+    c->scene.patches.reserve(c->scene.patches.size() + n_patch);
+    for (uint32_t i = 0; i < n_patch; ++i) {
+        pm::HostPatch h;
+        for (int k = 0; k < 4; ++k) std::memcpy(h.p[k], pos + 3 * (size_t)idx4[4 * i + k], 12);
+        h.flip_normal = (reverse_orientation != 0) != (swaps != 0);
+        h.prim_id = c->scene.next_prim_id++;
+        h.bounds = box_of_points(h.p, 4);   // bilinear_patch.rs:176-181
+        c->scene.patches.push_back(h);
+    }
+    c->accel_valid = false;
+    return PM_OK;
+}
+
+extern "C" int pm_add_triangle_mesh(pm_ctx* c, const float* pos, uint32_t n_vert, const uint32_t* idx3, uint32_t n_tri,
+                                    uint32_t* first) {
+    if (!c || !pos || (!idx3 && n_tri)) return fail(c, PM_ERR_INVALID, "pm_add_triangle_mesh: null argument");
+    for (uint64_t i = 0; i < (uint64_t)n_tri * 3; ++i)
+        if (idx3[i] >= n_vert) return fail(c, PM_ERR_INVALID, "pm_add_triangle_mesh: vertex index out of range");
+    if (first) *first = c->scene.next_prim_id;
+    c->scene.tris.reserve(c->scene.tris.size() + n_tri);
+    for (uint32_t i = 0; i < n_tri; ++i) {
+        pm::HostTri h;
+        for (int k = 0; k < 3; ++k) std::memcpy(h.v[k], pos + 3 * (size_t)idx3[3 * i + k], 12);
+        h.prim_id = c->scene.next_prim_id++;
+        h.bounds = box_of_points(h.v, 3);
+        c->scene.tris.push_back(h);
+    }
+    c->accel_valid = false;
+    return PM_OK;
+}
+
+extern "C" int pm_clear_geometry(pm_ctx* c) {
+    if (!c) return PM_ERR_INVALID;
+    c->scene = pm::HostScene();
+    c->accel_valid = false;
+    return PM_OK;
+}
+
+extern "C" int pm_build_accel(pm_ctx* c, int split_method, int max_prims_in_node, PmAccelInfo* info) {
+    if (!c) return PM_ERR_INVALID;
+    if (split_method < PM_SPLIT_HLBVH || split_method > PM_SPLIT_EQUAL_COUNTS)
+        return fail(c, PM_ERR_INVALID, "pm_build_accel: unknown split method");
+    if (c->device >= 0) HIPCHK(c, hipSetDevice(c->device));
+    c->split_method = split_method;
+    std::string err;
+    // the reference's max_prims_in_node is u8 (main.rs passes 255); wide leaves hold at most PM_MAX_LEAF
+    if (pm::build_accel(c->scene, max_prims_in_node, c->accel, err) != 0) return fail(c, PM_ERR_INVALID, "pm_build_accel: " + err);
+    const size_t nb = c->accel.nodes.size() * sizeof(PmWideNode), pb = c->accel.prims.size();
+    if (c->device >= 0) {
+        if (c->d_nodes) { HIPCHK(c, hipFree(c->d_nodes)); c->d_nodes = nullptr; }
+        if (c->d_prims) { HIPCHK(c, hipFree(c->d_prims)); c->d_prims = nullptr; }
+        HIPCHK(c, hipMalloc((void**)&c->d_nodes, nb));
+        HIPCHK(c, hipMalloc((void**)&c->d_prims, pb ? pb : 16));
+        HIPCHK(c, hipMemcpy(c->d_nodes, c->accel.nodes.data(), nb, hipMemcpyHostToDevice));
+        if (pb) HIPCHK(c, hipMemcpy(c->d_prims, c->accel.prims.data(), pb, hipMemcpyHostToDevice));
+    }
+    c->accel_valid = true;
+    if (info) {
+        info->n_prims = c->scene.next_prim_id;
+        info->n_nodes = (uint32_t)c->accel.nodes.size();
+        info->node_bytes = sizeof(PmWideNode);
+        info->prim_record_bytes[0] = sizeof(PmSphereRecord);
+        info->prim_record_bytes[1] = sizeof(PmPatchRecord);
+        info->prim_record_bytes[2] = sizeof(PmTriRecord);
+        info->node_buffer_bytes = nb; info->prim_buffer_bytes = pb;
+        for (int k = 0; k < 3; ++k) { info->bounds[k] = c->accel.bounds.lo[k]; info->bounds[3 + k] = c->accel.bounds.hi[k]; }
+        info->build_seconds = c->accel.build_seconds;
+    }
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------------------------------ trace
+template <bool ANY>
+static int trace_impl(pm_ctx* c, const PmRay* rays, uint64_t n, void* out, size_t out_elem) {
+    if (!c) return PM_ERR_INVALID;
+    if (c->device < 0) return fail(c, PM_ERR_INVALID, "trace: host-only context (pm_create(-1)) cannot launch kernels");
+    if (!c->accel_valid) return fail(c, PM_ERR_NO_ACCEL, "trace: pm_build_accel has not been called");
+    if (n == 0) { c->last_ms = 0.f; return PM_OK; }
+    if (!rays || !out) return fail(c, PM_ERR_INVALID, "trace: null rays/out");
+    if (n > (uint64_t)TRACE_BLOCK * 0x7FFFFFFFull) return fail(c, PM_ERR_INVALID, "trace: too many rays in one call");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool in_dev = is_device_ptr(rays), out_dev = is_device_ptr(out);
+    const PmRay* d_rays = rays;
+    void* d_out = out;
+    if (!in_dev) {
+        int r = ensure(c, &c->d_stage_in, &c->stage_in_cap, n * sizeof(PmRay));
+        if (r) return r;
+        HIPCHK(c, hipMemcpyAsync(c->d_stage_in, rays, n * sizeof(PmRay), hipMemcpyHostToDevice, c->stream));
+        d_rays = (const PmRay*)c->d_stage_in;
+    }
+    if (!out_dev) {
+        int r = ensure(c, &c->d_stage_out, &c->stage_out_cap, n * out_elem);
+        if (r) return r;
+        d_out = c->d_stage_out;
+    }
+    unsigned long long before[4];
+    HIPCHK(c, hipMemcpyAsync(before, c->d_counters, sizeof(before), hipMemcpyDeviceToHost, c->stream));
+    const uint32_t grid = (uint32_t)((n + TRACE_BLOCK - 1) / TRACE_BLOCK);
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (c->counting)
+        hipLaunchKernelGGL((trace_kernel<ANY, true>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_nodes, c->d_prims,
+                           d_rays, n, ANY ? nullptr : (PmHit*)d_out, ANY ? (uint8_t*)d_out : nullptr, c->d_counters);
+    else
+        hipLaunchKernelGGL((trace_kernel<ANY, false>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_nodes, c->d_prims,
+                           d_rays, n, ANY ? nullptr : (PmHit*)d_out, ANY ? (uint8_t*)d_out : nullptr, c->d_counters);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    if (!out_dev) HIPCHK(c, hipMemcpyAsync(out, d_out, n * out_elem, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long after[4];
+    HIPCHK(c, hipMemcpyAsync(after, c->d_counters, sizeof(after), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    if (c->counting) c->rays_counted += n;
+    if (after[3] != before[3]) return fail(c, PM_ERR_STACK_OVERFLOW, "trace: traversal stack overflow");
+    return PM_OK;
+}
+extern "C" int pm_trace_closest(pm_ctx* c, const PmRay* rays, uint64_t n, PmHit* out) {
+    return trace_impl<false>(c, rays, n, out, sizeof(PmHit));
+}
+extern "C" int pm_trace_any(pm_ctx* c, const PmRay* rays, uint64_t n, uint8_t* out) {
+    return trace_impl<true>(c, rays, n, out, 1);
+}
+
+// ------------------------------------------------------------------------------------------ measurement
+extern "C" int pm_set_counting(pm_ctx* c, int enabled) { if (!c) return PM_ERR_INVALID; c->counting = enabled != 0; return PM_OK; }
+extern "C" int pm_reset_counters(pm_ctx* c) {
+    if (!c || c->device < 0) return PM_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemset(c->d_counters, 0, 4 * sizeof(unsigned long long)));
+    c->rays_counted = 0;
+    return PM_OK;
+}
+extern "C" int pm_get_counters(pm_ctx* c, PmCounters* out) {
+    if (!c || !out || c->device < 0) return PM_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long v[4];
+    HIPCHK(c, hipMemcpy(v, c->d_counters, sizeof(v), hipMemcpyDeviceToHost));
+    out->rays = c->rays_counted; out->nodes_visited = v[1]; out->prims_tested = v[2]; out->stack_overflows = v[3];
+    return PM_OK;
+}
+extern "C" int pm_last_kernel_ms(pm_ctx* c, float* ms) { if (!c || !ms) return PM_ERR_INVALID; *ms = c->last_ms; return PM_OK; }
+extern "C" int pm_get_node_buffer(pm_ctx* c, void* data, uint64_t cap, uint64_t* needed) {
+    if (!c || !c->accel_valid) return fail(c, PM_ERR_NO_ACCEL, "no accel");
+    const uint64_t nb = c->accel.nodes.size() * sizeof(PmWideNode);
+    if (needed) *needed = nb;
+    if (data) { if (cap < nb) return fail(c, PM_ERR_INVALID, "buffer too small"); std::memcpy(data, c->accel.nodes.data(), nb); }
+    return PM_OK;
+}
+extern "C" int pm_get_prim_buffer(pm_ctx* c, void* data, uint64_t cap, uint64_t* needed) {
+    if (!c || !c->accel_valid) return fail(c, PM_ERR_NO_ACCEL, "no accel");
+    const uint64_t nb = c->accel.prims.size();
+    if (needed) *needed = nb;
+    if (data) { if (cap < nb) return fail(c, PM_ERR_INVALID, "buffer too small"); std::memcpy(data, c->accel.prims.data(), nb); }
+    return PM_OK;
+}

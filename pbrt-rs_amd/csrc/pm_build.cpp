@@ -1,0 +1,331 @@
+// Host-side construction of the wide (8-ary) quantised BVH.
+//
+// Reference counterpart: BVHAggregate::new / build_recursive / flatten_bvh
+// (primitives/aggregates.rs:25-271,476-529).  The reference builds a binary tree with 64-byte
+// nodes; closest-hit results do not depend on the tree shape (the leaf tests are the reference's
+// arithmetic, the box tests are conservative), so the GPU tree is free to be wide and quantised.
+// Pipeline: per-type binned-SAH binary build -> greedy collapse to 8 children (largest surface
+// area first) -> octant slot assignment (so slot ^ ray_octant is a front-to-back order) ->
+// outward-rounded 8-bit quantisation -> leaf records in traversal order.
+#include "pm_build.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <future>
+#include <limits>
+
+namespace pm {
+
+static inline Box box_union(const Box& a, const Box& b) {
+    Box r;
+    for (int i = 0; i < 3; ++i) { r.lo[i] = std::fmin(a.lo[i], b.lo[i]); r.hi[i] = std::fmax(a.hi[i], b.hi[i]); }
+    return r;
+}
+static inline Box box_empty() {
+    Box b;
+    for (int i = 0; i < 3; ++i) { b.lo[i] = std::numeric_limits<float>::max(); b.hi[i] = -std::numeric_limits<float>::max(); }
+    return b;
+}
+static inline float box_area(const Box& b) {
+    float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+    return 2.0f * (dx * dy + dx * dz + dy * dz);
+}
+
+struct BinNode { Box b; int left = -1, right = -1; uint32_t first = 0, count = 0; };
+
+struct BinBuilder {
+    const std::vector<Box>& pb;       // per-primitive boxes (indexed by local prim index)
+    std::vector<float> cen;           // centroids, 3 per prim
+    std::vector<uint32_t>& order;     // permutation being partitioned
+    int max_leaf;
+    BinBuilder(const std::vector<Box>& b, std::vector<uint32_t>& o, int ml) : pb(b), order(o), max_leaf(ml) {
+        cen.resize(b.size() * 3);
+        for (size_t i = 0; i < b.size(); ++i)
+            for (int k = 0; k < 3; ++k) cen[3 * i + k] = 0.5f * b[i].lo[k] + 0.5f * b[i].hi[k];
+    }
+    // builds nodes for order[lo,hi) into `out` (root is out[base]); returns root index
+    int build(std::vector<BinNode>& out, uint32_t lo, uint32_t hi, int depth) {
+        BinNode nd;
+        nd.b = box_empty();
+        Box cb = box_empty();
+        for (uint32_t i = lo; i < hi; ++i) {
+            uint32_t p = order[i];
+            nd.b = box_union(nd.b, pb[p]);
+            for (int k = 0; k < 3; ++k) {
+                cb.lo[k] = std::fmin(cb.lo[k], cen[3 * p + k]);
+                cb.hi[k] = std::fmax(cb.hi[k], cen[3 * p + k]);
+            }
+        }
+        uint32_t n = hi - lo;
+        int me = (int)out.size();
+        out.push_back(nd);
+        auto make_leaf = [&]() { out[me].first = lo; out[me].count = n; return me; };
+        if (n == 1) return make_leaf();
+        int dim = 0;
+        float ext[3] = {cb.hi[0] - cb.lo[0], cb.hi[1] - cb.lo[1], cb.hi[2] - cb.lo[2]};
+        if (ext[1] > ext[dim]) dim = 1;
+        if (ext[2] > ext[dim]) dim = 2;
+        uint32_t mid = lo;
+        bool split_done = false;
+        if (ext[dim] > 0.0f) {
+            const int NB = 16;
+            uint32_t cnt[NB] = {0};
+            Box bb[NB];
+            for (int i = 0; i < NB; ++i) bb[i] = box_empty();
+            float k1 = (float)NB * (1.0f - 1e-6f) / ext[dim];
+            auto bin_of = [&](uint32_t p) {
+                int b = (int)((cen[3 * p + dim] - cb.lo[dim]) * k1);
+                return b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+            };
+            for (uint32_t i = lo; i < hi; ++i) { int b = bin_of(order[i]); cnt[b]++; bb[b] = box_union(bb[b], pb[order[i]]); }
+            float right_area[NB]; uint32_t right_cnt[NB];
+            Box acc = box_empty(); uint32_t c = 0;
+            for (int i = NB - 1; i >= 1; --i) { acc = box_union(acc, bb[i]); c += cnt[i]; right_area[i] = box_area(acc); right_cnt[i] = c; }
+            acc = box_empty(); c = 0;
+            float best = std::numeric_limits<float>::infinity(); int best_i = -1;
+            for (int i = 0; i < NB - 1; ++i) {
+                acc = box_union(acc, bb[i]); c += cnt[i];
+                if (c == 0 || right_cnt[i + 1] == 0) continue;
+                float cost = (float)c * box_area(acc) + (float)right_cnt[i + 1] * right_area[i + 1];
+                if (cost < best) { best = cost; best_i = i; }
+            }
+            if (best_i >= 0) {
+                float leaf_cost = (float)n * box_area(nd.b);
+                // traversal cost 1 node ~ 1 prim test; only keep a leaf when it is small enough and cheaper
+                if (n <= (uint32_t)max_leaf && leaf_cost <= best + box_area(nd.b)) return make_leaf();
+                auto it = std::partition(order.begin() + lo, order.begin() + hi, [&](uint32_t p) { return bin_of(p) <= best_i; });
+                mid = (uint32_t)(it - order.begin());
+                split_done = mid > lo && mid < hi;
+            }
+        }
+        if (!split_done) {
+            if (n <= (uint32_t)max_leaf) return make_leaf();
+            mid = lo + n / 2;   // coincident centroids: split the index range
+            std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi,
+                             [&](uint32_t a, uint32_t b) { return cen[3 * a + dim] < cen[3 * b + dim]; });
+        }
+        int l, r;
+        if (n > 200000 && depth < 4) {
+            // large ranges: build the two halves concurrently into private vectors, then splice
+            std::vector<BinNode> lv, rv;
+            auto fl = std::async(std::launch::async, [&]() { return build(lv, lo, mid, depth + 1); });
+            int rr = build(rv, mid, hi, depth + 1);
+            int lr = fl.get();
+            int lbase = (int)out.size();
+            for (auto& x : lv) { if (x.left >= 0) { x.left += lbase; x.right += lbase; } out.push_back(x); }
+            int rbase = (int)out.size();
+            for (auto& x : rv) { if (x.left >= 0) { x.left += rbase; x.right += rbase; } out.push_back(x); }
+            l = lr + lbase; r = rr + rbase;
+        } else {
+            l = build(out, lo, mid, depth + 1);
+            r = build(out, mid, hi, depth + 1);
+        }
+        out[me].left = l; out[me].right = r;
+        return me;
+    }
+};
+
+// --- quantisation ---------------------------------------------------------------------------
+static inline float scale_of(uint8_t e) { uint32_t u = (uint32_t)e << 23; float f; std::memcpy(&f, &u, 4); return f; }
+
+static void quantise_node(PmWideNode& wn, const Box& nb, const Box* cb, const bool* used) {
+    for (int k = 0; k < 3; ++k) {
+        wn.o[k] = nb.lo[k];
+        float ext = nb.hi[k] - nb.lo[k];
+        int e = 127 - 126;   // smallest normal scale
+        if (ext > 0.0f) {
+            int ex; std::frexp(ext / 255.0f, &ex);   // ext/255 = m * 2^ex, m in [0.5,1)  -> 2^ex >= ext/255
+            e = ex + 127;
+        }
+        if (e < 1) e = 1;
+        for (;; ++e) {   // verify every child fits in 0..255 with outward rounding, else coarsen
+            float s = scale_of((uint8_t)e);
+            bool ok = true;
+            for (int c = 0; c < 8 && ok; ++c) {
+                if (!used[c]) continue;
+                float qh = std::ceil((cb[c].hi[k] - wn.o[k]) / s);
+                if (!(qh <= 254.0f)) ok = false;   // leave one step of head-room for the fix-up loop
+            }
+            if (ok || e >= 254) break;
+        }
+        wn.e[k] = (uint8_t)e;
+        float s = scale_of(wn.e[k]);
+        for (int c = 0; c < 8; ++c) {
+            if (!used[c]) { wn.qlo[k][c] = 255; wn.qhi[k][c] = 0; continue; }   // inverted box: never hit
+            int ql = (int)std::floor((cb[c].lo[k] - wn.o[k]) / s);
+            int qh = (int)std::ceil((cb[c].hi[k] - wn.o[k]) / s);
+            ql = std::max(0, std::min(255, ql));
+            qh = std::max(0, std::min(255, qh));
+            while (ql > 0 && std::fmaf((float)ql, s, wn.o[k]) > cb[c].lo[k]) --ql;
+            while (qh < 255 && std::fmaf((float)qh, s, wn.o[k]) < cb[c].hi[k]) ++qh;
+            wn.qlo[k][c] = (uint8_t)ql;
+            wn.qhi[k][c] = (uint8_t)qh;
+        }
+    }
+}
+
+struct Collapser {
+    const std::vector<BinNode>& bn;
+    const std::vector<uint32_t>& order;   // local prim order of this type
+    int type;
+    Accel& acc;
+    const HostScene& sc;
+    const std::vector<uint32_t>& local_to_global;   // local prim index -> index into per-type arrays
+
+    void emit_record(uint32_t local) {
+        uint32_t gi = local_to_global[local];
+        if (type == PM_PRIM_TRI) {
+            PmTriRecord r{};
+            const HostTri& t = sc.tris[gi];
+            std::memcpy(r.v0, t.v[0], 12); std::memcpy(r.v1, t.v[1], 12); std::memcpy(r.v2, t.v[2], 12);
+            r.prim_id = t.prim_id;
+            size_t off = acc.prims.size(); acc.prims.resize(off + sizeof(r)); std::memcpy(&acc.prims[off], &r, sizeof(r));
+        } else if (type == PM_PRIM_PATCH) {
+            PmPatchRecord r{};
+            const HostPatch& p = sc.patches[gi];
+            std::memcpy(r.p00, p.p[0], 12); std::memcpy(r.p10, p.p[1], 12); std::memcpy(r.p01, p.p[2], 12); std::memcpy(r.p11, p.p[3], 12);
+            r.prim_id = p.prim_id; r.flags = p.flip_normal ? 1u : 0u;
+            size_t off = acc.prims.size(); acc.prims.resize(off + sizeof(r)); std::memcpy(&acc.prims[off], &r, sizeof(r));
+        } else {
+            PmSphereRecord r{};
+            const HostSphere& s = sc.spheres[gi];
+            std::memcpy(r.ofr, s.object_from_render, 48);
+            r.radius = s.radius; r.z_min = s.z_min; r.z_max = s.z_max; r.phi_max = s.phi_max;
+            r.prim_id = s.prim_id; r.flags = s.reverse_orientation ? 1u : 0u;
+            size_t off = acc.prims.size(); acc.prims.resize(off + sizeof(r)); std::memcpy(&acc.prims[off], &r, sizeof(r));
+        }
+    }
+
+    // Fill wide node `wi` from binary subtree rooted at `b`; queue gets (wide index, binary index) of interior children.
+    void fill(uint32_t wi, int b, std::vector<std::pair<uint32_t, int>>& queue) {
+        int kids[8]; int nk = 0;
+        if (bn[b].left < 0) { kids[nk++] = b; }
+        else { kids[nk++] = bn[b].left; kids[nk++] = bn[b].right; }
+        // greedy expansion: open the interior child with the largest surface area
+        for (;;) {
+            if (nk >= 8) break;
+            int best = -1; float ba = -1.0f;
+            for (int i = 0; i < nk; ++i)
+                if (bn[kids[i]].left >= 0) { float a = box_area(bn[kids[i]].b); if (a > ba) { ba = a; best = i; } }
+            if (best < 0) break;
+            int k = kids[best];
+            kids[best] = bn[k].left; kids[nk++] = bn[k].right;
+        }
+        // octant slot assignment: maximise dot(child centroid - node centroid, slot direction), greedily
+        const Box& nb = bn[b].b;
+        float pc[3] = {0.5f * (nb.lo[0] + nb.hi[0]), 0.5f * (nb.lo[1] + nb.hi[1]), 0.5f * (nb.lo[2] + nb.hi[2])};
+        float cost[8][8];
+        for (int i = 0; i < nk; ++i) {
+            const Box& cbx = bn[kids[i]].b;
+            float d[3] = {0.5f * (cbx.lo[0] + cbx.hi[0]) - pc[0], 0.5f * (cbx.lo[1] + cbx.hi[1]) - pc[1], 0.5f * (cbx.lo[2] + cbx.hi[2]) - pc[2]};
+            for (int s = 0; s < 8; ++s)
+                cost[i][s] = ((s & 1) ? d[0] : -d[0]) + ((s & 2) ? d[1] : -d[1]) + ((s & 4) ? d[2] : -d[2]);
+        }
+        int slot_of[8]; bool child_done[8] = {false}, slot_used[8] = {false};
+        for (int it = 0; it < nk; ++it) {
+            int bi = -1, bs = -1; float bc = -std::numeric_limits<float>::infinity();
+            for (int i = 0; i < nk; ++i) if (!child_done[i])
+                for (int s = 0; s < 8; ++s) if (!slot_used[s] && cost[i][s] > bc) { bc = cost[i][s]; bi = i; bs = s; }
+            slot_of[bi] = bs; child_done[bi] = true; slot_used[bs] = true;
+        }
+        int in_slot[8]; for (int s = 0; s < 8; ++s) in_slot[s] = -1;
+        for (int i = 0; i < nk; ++i) in_slot[slot_of[i]] = kids[i];
+
+        PmWideNode wn{};
+        Box cb[8]; bool used[8];
+        uint8_t imask = 0; uint32_t n_int = 0;
+        for (int s = 0; s < 8; ++s) {
+            used[s] = in_slot[s] >= 0;
+            if (used[s]) { cb[s] = bn[in_slot[s]].b; if (bn[in_slot[s]].left >= 0) { imask |= (uint8_t)(1u << s); ++n_int; } }
+        }
+        quantise_node(wn, nb, cb, used);
+        wn.imask = imask;
+        wn.child_base = (uint32_t)acc.nodes.size();
+        uint32_t prim_base_units = (uint32_t)(acc.prims.size() / 16);
+        wn.prim_base = prim_base_units | ((uint32_t)type << 30);
+        uint32_t rec_off = 0;
+        // reserve interior children contiguously, in slot order
+        acc.nodes.resize(acc.nodes.size() + n_int);
+        uint32_t rank = 0;
+        for (int s = 0; s < 8; ++s) {
+            if (!used[s]) { wn.meta[s] = 0; continue; }
+            const BinNode& c = bn[in_slot[s]];
+            if (c.left >= 0) {
+                wn.meta[s] = 0;
+                queue.emplace_back(wn.child_base + rank, in_slot[s]);
+                ++rank;
+            } else {
+                wn.meta[s] = (uint8_t)((c.count << 5) | rec_off);
+                for (uint32_t i = 0; i < c.count; ++i) emit_record(order[c.first + i]);
+                rec_off += c.count;
+            }
+        }
+        acc.nodes[wi] = wn;
+    }
+
+    void run(uint32_t root_wide, int root_bin) {
+        std::vector<std::pair<uint32_t, int>> queue;
+        queue.emplace_back(root_wide, root_bin);
+        size_t head = 0;
+        while (head < queue.size()) {
+            auto [wi, b] = queue[head++];
+            fill(wi, b, queue);
+        }
+    }
+};
+
+int build_accel(const HostScene& sc, int max_leaf, Accel& acc, std::string& err) {
+    auto t0 = std::chrono::steady_clock::now();
+    acc.nodes.clear(); acc.prims.clear();
+    if (max_leaf < 1) max_leaf = 1;
+    if (max_leaf > PM_MAX_LEAF) max_leaf = PM_MAX_LEAF;
+    size_t n_total = sc.spheres.size() + sc.patches.size() + sc.tris.size();
+    if (n_total == 0) { err = "no primitives"; return 1; }
+
+    struct TypeTree { int type; std::vector<Box> boxes; std::vector<uint32_t> order, l2g; std::vector<BinNode> bn; int root; };
+    std::vector<TypeTree> trees;
+    auto add_type = [&](int type, size_t n, auto box_fn) {
+        if (n == 0) return;
+        trees.emplace_back();
+        TypeTree& t = trees.back();
+        t.type = type; t.boxes.resize(n); t.order.resize(n); t.l2g.resize(n);
+        for (size_t i = 0; i < n; ++i) { t.boxes[i] = box_fn(i); t.order[i] = (uint32_t)i; t.l2g[i] = (uint32_t)i; }
+        BinBuilder bb(t.boxes, t.order, max_leaf);
+        t.bn.reserve(2 * n);
+        t.root = bb.build(t.bn, 0, (uint32_t)n, 0);
+    };
+    add_type(PM_PRIM_SPHERE, sc.spheres.size(), [&](size_t i) { return sc.spheres[i].bounds; });
+    add_type(PM_PRIM_PATCH, sc.patches.size(), [&](size_t i) { return sc.patches[i].bounds; });
+    add_type(PM_PRIM_TRI, sc.tris.size(), [&](size_t i) { return sc.tris[i].bounds; });
+
+    Box total = box_empty();
+    for (auto& t : trees) total = box_union(total, t.bn[t.root].b);
+    acc.bounds = total;
+
+    if (trees.size() == 1) {
+        acc.nodes.resize(1);
+        Collapser c{trees[0].bn, trees[0].order, trees[0].type, acc, sc, trees[0].l2g};
+        c.run(0, trees[0].root);
+    } else {
+        // join node: one interior child per primitive type
+        acc.nodes.resize(1 + trees.size());
+        PmWideNode wn{};
+        Box cb[8]; bool used[8] = {false};
+        for (size_t i = 0; i < trees.size(); ++i) { cb[i] = trees[i].bn[trees[i].root].b; used[i] = true; }
+        quantise_node(wn, total, cb, used);
+        wn.imask = (uint8_t)((1u << trees.size()) - 1);
+        wn.child_base = 1; wn.prim_base = 0;
+        acc.nodes[0] = wn;
+        for (size_t i = 0; i < trees.size(); ++i) {
+            Collapser c{trees[i].bn, trees[i].order, trees[i].type, acc, sc, trees[i].l2g};
+            c.run(1 + (uint32_t)i, trees[i].root);
+        }
+    }
+    acc.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+}  // namespace pm

@@ -1,0 +1,47 @@
+// Host-side scene storage and acceleration-structure build (internal to libpbrt_mi355.so).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "pm_layout.h"
+
+namespace pm {
+
+struct Box { float lo[3], hi[3]; };
+
+struct HostSphere {
+    float radius, z_min, z_max, phi_max, theta_z_min, theta_z_max;
+    float render_from_object[16], object_from_render[16];
+    bool reverse_orientation;
+    uint32_t prim_id;
+    Box bounds;
+};
+struct HostPatch {
+    float p[4][3];      // p00 p10 p01 p11
+    bool flip_normal;
+    uint32_t prim_id;
+    Box bounds;
+};
+struct HostTri {
+    float v[3][3];
+    uint32_t prim_id;
+    Box bounds;
+};
+
+struct HostScene {
+    std::vector<HostSphere> spheres;
+    std::vector<HostPatch> patches;
+    std::vector<HostTri> tris;
+    uint32_t next_prim_id = 0;
+};
+
+struct Accel {
+    std::vector<PmWideNode> nodes;
+    std::vector<uint8_t> prims;     // leaf records, 16-byte units
+    Box bounds;
+    double build_seconds = 0.0;
+};
+
+int build_accel(const HostScene& sc, int max_leaf, Accel& acc, std::string& err);
+
+}  // namespace pm

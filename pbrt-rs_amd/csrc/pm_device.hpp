@@ -1,0 +1,352 @@
+// Device-side arithmetic and BVH traversal for gfx950 (wave64).  Compiled with -ffp-contract=off:
+// every leaf test below must round exactly like the reference's Rust (which never fuses a*b+c and
+// computes cross products in f64), so that hit ids / t / (u,v) are bit-identical to the CPU path.
+//
+// Reference arithmetic restated here:
+//   ray/patch      shapes/bilinear_patch.rs:506-612, math.rs:42-87, core/square_matrix.rs:123-138
+//   ray/sphere     shapes/sphere.rs:265-368, core/interval.rs, core/transform.rs:338-433
+//   ray/box        core/bounds.rs:381-404 (same widening; applied to the de-quantised child boxes)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pm_layout.h"
+
+namespace pmd {
+
+#define PMD __device__ __forceinline__
+
+struct f3 { float x, y, z; };
+PMD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PMD f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PMD f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PMD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+PMD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+PMD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+PMD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PMD f3 cross3(f3 a, f3 b) {   // f64 products, one narrowing (core/vec.rs:700-712)
+    double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z;
+    return mk3((float)(ay * bz - az * by), (float)(az * bx - ax * bz), (float)(ax * by - ay * bx));
+}
+PMD f3 lerp3(f3 a, f3 b, float t) { return a * (1.0f - t) + b * t; }
+PMD f3 abs3(f3 a) { return mk3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
+PMD float maxc3(f3 a) { float m = a.x; if (!(a.y < m)) m = a.y; if (!(a.z < m)) m = a.z; return m; }
+PMD float len3(f3 a) { return sqrtf(dot3(a, a)); }
+PMD f3 norm3(f3 a) { return a / len3(a); }
+
+PMD float fup(float v) {      // next_float_up, core/float.rs:14-36
+    if ((isinf(v) && v > 0.0f) || isnan(v)) return v;
+    if (v == 0.0f) v = 0.0f;
+    uint32_t b = __float_as_uint(v);
+    return __uint_as_float((b >> 31) ? b - 1 : b + 1);
+}
+PMD float fdn(float v) {      // next_float_down, core/float.rs:40-60
+    if ((isinf(v) && v < 0.0f) || isnan(v)) return v;
+    if (v == 0.0f) v = -0.0f;
+    uint32_t b = __float_as_uint(v);
+    return __uint_as_float((b >> 31) ? b + 1 : b - 1);
+}
+#define PMD_EPS 5.9604644775390625e-08f
+PMD float gamma_n(int n) { float nf = (float)n; return (PMD_EPS * nf) / (1.0f - nf * PMD_EPS); }
+
+PMD float dop(float a, float b, float c, float d) {   // math.rs:78-87
+    float cd = c * d;
+    float r = __fmaf_rn(a, b, -cd);
+    float e = __fmaf_rn(-c, d, cd);
+    return r + e;
+}
+PMD float det3(float m00, float m01, float m02, float m10, float m11, float m12, float m20, float m21, float m22) {
+    float minor12 = dop(m11, m22, m12, m21);
+    float minor02 = dop(m10, m22, m12, m20);
+    float minor01 = dop(m10, m21, m11, m20);
+    return __fmaf_rn(m02, minor01, dop(m00, minor12, m01, minor02));
+}
+
+// ---------------------------------------------------------------------------------- patch / triangle
+PMD bool patch_root(f3 ro, f3 rd, f3 p00, f3 p10, f3 p01, f3 p11, float uu, float* vnum, float* tnum, float* p2o) {
+    f3 uo = lerp3(p00, p10, uu);
+    f3 ud = lerp3(p01, p11, uu) - uo;
+    f3 dl = uo - ro;
+    f3 perp = cross3(rd, ud);
+    *p2o = dot3(perp, perp);
+    *vnum = det3(dl.x, rd.x, perp.x, dl.y, rd.y, perp.y, dl.z, rd.z, perp.z);
+    *tnum = det3(dl.x, ud.x, perp.x, dl.y, ud.y, perp.y, dl.z, ud.z, perp.z);
+    return true;
+}
+// returns true and (t,u,v) iff the reference's intersect_bilinear_patch returns Some for this t_max
+PMD bool intersect_patch(f3 ro, f3 rd, float t_max, f3 p00, f3 p10, f3 p01, f3 p11, float* to, float* uo, float* vo) {
+    float a = dot3(cross3(p10 - p00, p01 - p11), rd);
+    float c = dot3(cross3(p00 - ro, rd), p01 - p00);
+    float b = dot3(cross3(p10 - ro, rd), p11 - p10) - (a + c);
+    float u1, u2;
+    if (a == 0.0f) {
+        if (b == 0.0f) return false;   // (all-zero coefficients assert in the reference; a miss here)
+        u1 = -c / b; u2 = u1;
+    } else {
+        float disc = dop(b, b, 4.0f * a, c);
+        if (disc < 0.0f) return false;
+        float rt = sqrtf(disc);
+        float q = -0.5f * (b + copysignf(rt, b));
+        float r0 = q / a, r1 = c / q;
+        if (r0 <= r1) { u1 = r0; u2 = r1; } else { u1 = r1; u2 = r0; }
+    }
+    float eps = gamma_n(10) * (maxc3(abs3(ro)) + maxc3(abs3(rd)) + maxc3(abs3(p00)) + maxc3(abs3(p10)) +
+                               maxc3(abs3(p01)) + maxc3(abs3(p11)));
+    float t = t_max, u = 0.0f, v = 0.0f;
+    if (u1 >= 0.0f && u1 <= 1.0f) {
+        float vn, tn, p2;
+        patch_root(ro, rd, p00, p10, p01, p11, u1, &vn, &tn, &p2);
+        if (tn > p2 * eps && (vn >= 0.0f && vn <= p2)) { u = u1; v = vn / p2; t = tn / p2; }
+    }
+    if (u2 >= 0.0f && u2 <= 1.0f && u2 != u1) {
+        float vn, tn, p2;
+        patch_root(ro, rd, p00, p10, p01, p11, u2, &vn, &tn, &p2);
+        float t2 = tn / p2;               // B10: divided before the epsilon compare
+        if (t2 > p2 * eps && (vn >= 0.0f && vn <= p2) && t2 < t) { u = u2; v = vn / p2; t = t2; }
+    }
+    if (t < t_max) { *to = t; *uo = u; *vo = v; return true; }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------- intervals / sphere
+struct Iv { float lo, hi; };
+PMD Iv iv(float l, float h) { Iv r; r.lo = l; r.hi = h; return r; }
+PMD Iv iv_exact(float v) { return iv(v, v); }
+PMD Iv iv_err(float v, float e) { return e == 0.0f ? iv(v, v) : iv(fdn(v - e), fup(v + e)); }
+PMD float iv_mid(Iv a) { return (a.lo + a.hi) / 2.0f; }
+PMD Iv operator+(Iv a, Iv b) { return iv(fdn(a.lo + b.lo), fup(a.hi + b.hi)); }
+PMD Iv operator-(Iv a, Iv b) { return iv(fdn(a.lo - b.hi), fup(a.hi - b.lo)); }
+PMD Iv operator*(Iv a, Iv b) {
+    float p0 = a.lo * b.lo, p1 = a.lo * b.hi, p2 = a.hi * b.lo, p3 = a.hi * b.hi;
+    return iv(fdn(fminf(fminf(fminf(p0, p1), p2), p3)), fup(fmaxf(fmaxf(fmaxf(p0, p1), p2), p3)));
+}
+PMD Iv operator*(Iv a, float f) { return f > 0.0f ? iv(fdn(a.lo * f), fup(a.hi * f)) : iv(fdn(a.hi * f), fup(a.lo * f)); }
+PMD Iv operator*(float f, Iv a) { return f > 0.0f ? iv(fdn(f * a.lo), fup(f * a.hi)) : iv(fdn(f * a.hi), fup(f * a.lo)); }
+PMD Iv operator/(Iv a, Iv b) {
+    if (b.lo < 0.0f && b.hi > 0.0f) return iv(-INFINITY, INFINITY);
+    float q0 = a.lo / b.lo, q1 = a.lo / b.hi, q2 = a.hi / b.lo, q3 = a.hi / b.hi;
+    return iv(fdn(fminf(fminf(fminf(q0, q1), q2), q3)), fup(fmaxf(fmaxf(fmaxf(q0, q1), q2), q3)));
+}
+PMD Iv iv_sq(Iv a) {
+    if (a.lo >= 0.0f) return iv(fdn(a.lo * a.lo), fup(a.hi * a.hi));
+    if (a.hi <= 0.0f) return iv(fdn(a.hi * a.hi), fup(a.lo * a.lo));
+    float m = fmaxf(fabsf(a.lo), fabsf(a.hi));
+    return iv(0.0f, fup(m * m));
+}
+PMD Iv iv_sqrt(Iv a) { return iv(fmaxf(fdn(sqrtf(a.lo)), 0.0f), fup(sqrtf(a.hi))); }
+
+struct SphereHit { float t; f3 p_obj; float phi; };
+
+// Transform * Point3fi for an exact input point and an affine matrix (rows 0..2 in m[12]).
+PMD void xf_point_exact(const float* m, f3 p, Iv* ox, Iv* oy, Iv* oz) {
+    float g3 = gamma_n(3);
+    float xp = (m[0] * p.x + m[1] * p.y) + (m[2] * p.z + m[3]);
+    float yp = (m[4] * p.x + m[5] * p.y) + (m[6] * p.z + m[7]);
+    float zp = (m[8] * p.x + m[9] * p.y) + (m[10] * p.z + m[11]);
+    float ex = g3 * (fabsf(m[0] * p.x) + fabsf(m[1] * p.y) + fabsf(m[2] * p.z) + fabsf(m[3]));
+    float ey = g3 * (fabsf(m[4] * p.x) + fabsf(m[5] * p.y) + fabsf(m[6] * p.z) + fabsf(m[7]));
+    float ez = g3 * (fabsf(m[8] * p.x) + fabsf(m[9] * p.y) + fabsf(m[10] * p.z) + fabsf(m[11]));
+    *ox = iv_err(xp, ex); *oy = iv_err(yp, ey); *oz = iv_err(zp, ez);
+}
+PMD void xf_vec_exact(const float* m, f3 v, Iv* ox, Iv* oy, Iv* oz) {
+    Iv x = iv_exact(v.x), y = iv_exact(v.y), z = iv_exact(v.z);
+    *ox = x * m[0] + y * m[1] + z * m[2];
+    *oy = x * m[4] + y * m[5] + z * m[6];
+    *oz = x * m[8] + y * m[9] + z * m[10];
+}
+
+PMD void sphere_point_phi(f3 om, f3 dm, float tm, float radius, f3* p, float* phi) {
+    f3 ph = om + dm * tm;
+    ph = ph * (radius / len3(ph));
+    if (ph.x == 0.0f && ph.y == 0.0f) ph.x = 1e-5f * radius;
+    float f = atan2f(ph.y, ph.x);
+    if (f <= 0.0f) f += 2.0f * 3.14159265358979323846f;
+    *p = ph; *phi = f;
+}
+
+PMD bool intersect_sphere(f3 ro, f3 rd, float t_max, const float* ofr, float radius, float z_min, float z_max,
+                          float phi_max, SphereHit* out) {
+    Iv ox, oy, oz, dx, dy, dz;
+    xf_point_exact(ofr, ro, &ox, &oy, &oz);
+    xf_vec_exact(ofr, rd, &dx, &dy, &dz);
+    Iv a = iv_sq(dx) + iv_sq(dy) + iv_sq(dz);
+    Iv b = 2.0f * (dx * ox + dy * oy + dz * oz);
+    Iv c = iv_sq(ox) + iv_sq(oy) + iv_sq(oz) - iv_sq(iv_exact(radius));
+    Iv f = b / (2.0f * a);
+    Iv vx = ox - dx * f, vy = oy - dy * f, vz = oz - dz * f;
+    Iv len = iv_sqrt(iv_sq(vx) + iv_sq(vy) + iv_sq(vz));
+    Iv disc = 4.0f * a * (iv_exact(radius) + len) * (iv_exact(radius) - len);
+    if (disc.lo < 0.0f) return false;
+    Iv rdisc = iv_sqrt(disc);
+    Iv q = (iv_mid(b) < 0.0f) ? -0.5f * (b - rdisc) : -0.5f * (b + rdisc);
+    Iv t0 = q / a, t1 = c / q;
+    if (t0.lo > t1.lo) { Iv tmp = t0; t0 = t1; t1 = tmp; }
+    if (t0.hi > t_max || t1.lo <= 0.0f) return false;
+    Iv ts;
+    bool is_t1 = false;
+    if (t0.lo > 0.0f) ts = t0;
+    else if (t1.hi <= t_max) { ts = t1; is_t1 = true; }
+    else return false;
+    f3 om = mk3(iv_mid(ox), iv_mid(oy), iv_mid(oz));
+    f3 dm = mk3(iv_mid(dx), iv_mid(dy), iv_mid(dz));
+    f3 ph; float phi;
+    sphere_point_phi(om, dm, iv_mid(ts), radius, &ph, &phi);
+    bool clip = (z_min > -radius && ph.z < z_min) || (z_max < radius && ph.z > z_max) || phi > phi_max;
+    if (clip) {
+        // sphere.rs:345 compares the intervals (t_shape_hit == t1), not which branch produced them
+        if (is_t1 || (ts.lo == t1.lo && ts.hi == t1.hi) || t1.hi > t_max) return false;
+        ts = t1;
+        sphere_point_phi(om, dm, iv_mid(ts), radius, &ph, &phi);
+        clip = (z_min > -radius && ph.z < z_min) || (z_max < radius && ph.z > z_max) || phi > phi_max;
+        if (clip) return false;
+    }
+    out->t = iv_mid(ts); out->p_obj = ph; out->phi = phi;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------- traversal
+struct Ray { f3 o, d; float tmax; };
+struct HitRec { uint32_t prim_id; float t, u, v; };
+
+PMD uint32_t perm8(uint32_t m, uint32_t oct) {   // bit k of result = bit (k ^ oct) of m
+    if (oct & 1) m = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u);
+    if (oct & 2) m = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u);
+    if (oct & 4) m = ((m & 0x0Fu) << 4) | ((m >> 4) & 0x0Fu);
+    return m;
+}
+PMD float ubyte(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }
+
+struct TravCounters { uint32_t nodes, prims, overflow; };
+
+// One ray through the wide BVH.  ANY: stop at the first accepted primitive (intersect_p);
+// otherwise shrink tmax on every accepted primitive (intersect).  `lds` is this lane's column of
+// the per-block LDS stack: entry e of lane l lives at lds[e * stride + l].
+template <bool ANY, bool COUNT>
+PMD bool traverse(const PmWideNode* __restrict__ nodes, const uint4* __restrict__ prims, Ray ray, HitRec* hit,
+                  uint2* lds, int stride, TravCounters* ctr) {
+    const float widen = 1.0f + 2.0f * gamma_n(3);
+    const f3 inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    const uint32_t oct = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
+    float tmax = ray.tmax;
+    bool found = false;
+    hit->prim_id = 0xFFFFFFFFu; hit->t = tmax; hit->u = 0.0f; hit->v = 0.0f;
+
+    uint2 spill[PM_SPILL_STACK];
+    int sp = 0;
+    // current group: x = child_base, y = (imask << 8) | permuted hit mask.  Start with a pseudo group
+    // holding only the root (index 0).
+    uint2 cur = make_uint2(0u, (1u << 8) | perm8(1u, oct));
+
+    for (;;) {
+        uint32_t pm = cur.y & 0xFFu;
+        if (pm == 0u) {
+            if (sp == 0) break;
+            --sp;
+            cur = sp < PM_LDS_STACK ? lds[sp * stride] : spill[sp - PM_LDS_STACK];
+            continue;
+        }
+        const uint32_t k = __ffs(pm) - 1u;
+        const uint32_t slot = k ^ oct;
+        const uint32_t imask_g = cur.y >> 8;
+        const uint32_t nidx = cur.x + __popc(imask_g & ((1u << slot) - 1u));
+        cur.y &= ~(1u << k);
+        if (cur.y & 0xFFu) {
+            if (sp < PM_LDS_STACK) lds[sp * stride] = cur;
+            else if (sp < PM_LDS_STACK + PM_SPILL_STACK) spill[sp - PM_LDS_STACK] = cur;
+            else { ctr->overflow = 1; --sp; }
+            ++sp;
+        }
+        // ---- fetch the 80-byte node (5 x 16 B)
+        const uint4* np = reinterpret_cast<const uint4*>(nodes + nidx);
+        const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+        if (COUNT) ctr->nodes++;
+        const float ox = __uint_as_float(n0.x), oy = __uint_as_float(n0.y), oz = __uint_as_float(n0.z);
+        const float sx = __uint_as_float((n0.w & 0xFFu) << 23);
+        const float sy = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23);
+        const float sz = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23);
+        const uint32_t imask = n0.w >> 24;
+        const uint32_t metaw[2] = {n1.z, n1.w};
+        const uint32_t qlx[2] = {n2.x, n2.y}, qly[2] = {n2.z, n2.w}, qlz[2] = {n3.x, n3.y};
+        const uint32_t qhx[2] = {n3.z, n3.w}, qhy[2] = {n4.x, n4.y}, qhz[2] = {n4.z, n4.w};
+        uint32_t hits = 0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int w = s >> 2, kk = s & 3;
+            const float lx = __fmaf_rn(ubyte(qlx[w], kk), sx, ox), hx = __fmaf_rn(ubyte(qhx[w], kk), sx, ox);
+            const float ly = __fmaf_rn(ubyte(qly[w], kk), sy, oy), hy = __fmaf_rn(ubyte(qhy[w], kk), sy, oy);
+            const float lz = __fmaf_rn(ubyte(qlz[w], kk), sz, oz), hz = __fmaf_rn(ubyte(qhz[w], kk), sz, oz);
+            float a = (lx - ray.o.x) * inv.x, b = (hx - ray.o.x) * inv.x;
+            float t0 = fmaxf(0.0f, fminf(a, b));
+            float t1 = fminf(tmax, fmaxf(a, b) * widen);
+            a = (ly - ray.o.y) * inv.y; b = (hy - ray.o.y) * inv.y;
+            t0 = fmaxf(t0, fminf(a, b));
+            t1 = fminf(t1, fmaxf(a, b) * widen);
+            a = (lz - ray.o.z) * inv.z; b = (hz - ray.o.z) * inv.z;
+            t0 = fmaxf(t0, fminf(a, b));
+            t1 = fminf(t1, fmaxf(a, b) * widen);
+            const bool valid = ((imask >> s) & 1u) || (((metaw[w] >> (8 * kk)) & 0xFFu) != 0u);
+            if (valid && !(t0 > t1)) hits |= 1u << s;
+        }
+        // ---- leaves of this node, front to back by octant order
+        uint32_t lm = perm8(hits & ~imask, oct);
+        const uint32_t ptype = n1.y >> 30;
+        const uint32_t pbase = n1.y & 0x3FFFFFFFu;
+        while (lm) {
+            const uint32_t kl = __ffs(lm) - 1u;
+            lm &= lm - 1u;
+            const uint32_t ls = kl ^ oct;
+            const uint32_t meta = (metaw[ls >> 2] >> (8 * (ls & 3))) & 0xFFu;
+            const uint32_t cnt = meta >> 5, off = meta & 31u;
+            for (uint32_t j = 0; j < cnt; ++j) {
+                if (COUNT) ctr->prims++;
+                if (ptype == PM_PRIM_TRI) {
+                    const uint4* r = prims + pbase + (off + j) * PM_UNITS_TRI;
+                    const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
+                    f3 v0 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
+                    f3 v1 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
+                    f3 v2 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
+                    float t, u, v;
+                    if (intersect_patch(ray.o, ray.d, tmax, v0, v1, v2, v2, &t, &u, &v)) {
+                        if (ANY) return true;
+                        tmax = t; found = true; hit->prim_id = r2.y; hit->t = t; hit->u = u; hit->v = v;
+                    }
+                } else if (ptype == PM_PRIM_PATCH) {
+                    const uint4* r = prims + pbase + (off + j) * PM_UNITS_PATCH;
+                    const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+                    f3 p00 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
+                    f3 p10 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
+                    f3 p01 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
+                    f3 p11 = mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
+                    float t, u, v;
+                    if (intersect_patch(ray.o, ray.d, tmax, p00, p10, p01, p11, &t, &u, &v)) {
+                        if (ANY) return true;
+                        tmax = t; found = true; hit->prim_id = r3.x; hit->t = t; hit->u = u; hit->v = v;
+                    }
+                } else {
+                    const uint4* r = prims + pbase + (off + j) * PM_UNITS_SPHERE;
+                    float m[12];
+                    const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+                    m[0] = __uint_as_float(r0.x); m[1] = __uint_as_float(r0.y); m[2] = __uint_as_float(r0.z); m[3] = __uint_as_float(r0.w);
+                    m[4] = __uint_as_float(r1.x); m[5] = __uint_as_float(r1.y); m[6] = __uint_as_float(r1.z); m[7] = __uint_as_float(r1.w);
+                    m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
+                    const float radius = __uint_as_float(r3.x), zmin = __uint_as_float(r3.y), zmax = __uint_as_float(r3.z),
+                                phimax = __uint_as_float(r3.w);
+                    SphereHit sh;
+                    if (intersect_sphere(ray.o, ray.d, tmax, m, radius, zmin, zmax, phimax, &sh)) {
+                        if (ANY) return true;
+                        tmax = sh.t; found = true; hit->prim_id = r4.x; hit->t = sh.t;
+                        // (u,v) of sphere.rs:382-385
+                        const float th0 = acosf(fminf(fmaxf(zmin / radius, -1.0f), 1.0f));
+                        const float th1 = acosf(fminf(fmaxf(zmax / radius, -1.0f), 1.0f));
+                        const float th = acosf(fminf(fmaxf(sh.p_obj.z / radius, -1.0f), 1.0f));
+                        hit->u = sh.phi / phimax; hit->v = (th - th0) / (th1 - th0);
+                    }
+                }
+            }
+        }
+        // ---- descend into the interior children that were hit
+        cur = make_uint2(n1.x, (imask << 8) | perm8(hits & imask, oct));
+    }
+    return found;
+}
+
+}  // namespace pmd

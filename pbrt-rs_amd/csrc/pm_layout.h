@@ -1,0 +1,50 @@
+// Device data layout of the wide quantised BVH and the leaf primitive records (HBM-resident).
+// Replaces the reference's 64-byte binary LinearBVHNode (primitives/aggregates.rs:719-732) and the
+// Vec<Arc<PrimitiveEnum>> -> Arc<ShapeEnum> -> mesh pointer chase (primitives/single.rs:72-75,
+// shapes/bilinear_patch.rs:700-707).
+#pragma once
+#include <stdint.h>
+
+// 80-byte 8-ary node.  Child boxes are stored as 8-bit offsets on a per-node power-of-two grid:
+//   plane = fmaf((float)q, 2^(e-127), o)      (single rounding; the builder rounds q outward
+//                                               against exactly this expression)
+// Children that are interior nodes (bit set in imask) live at child_base + rank(slot in imask).
+// Leaf children reference `count` consecutive records starting `offset` records after prim_base.
+// All leaf children of one node hold the same primitive type (type-homogeneous subtrees).
+struct alignas(16) PmWideNode {
+    float o[3];
+    uint8_t e[3];
+    uint8_t imask;
+    uint32_t child_base;
+    uint32_t prim_base;      // bits 0..29: first record, in 16-byte units; bits 30..31: PM_PRIM_* type
+    uint8_t meta[8];         // 0 = empty slot or interior; leaf: (count << 5) | offset (records)
+    uint8_t qlo[3][8];
+    uint8_t qhi[3][8];
+};
+static_assert(sizeof(PmWideNode) == 80, "node must be 80 bytes");
+
+enum { PM_PRIM_SPHERE = 0, PM_PRIM_PATCH = 1, PM_PRIM_TRI = 2 };
+
+// record sizes in 16-byte units
+#define PM_UNITS_SPHERE 5
+#define PM_UNITS_PATCH 4
+#define PM_UNITS_TRI 3
+
+struct alignas(16) PmTriRecord {      // 48 B: degenerate patch p00=v0 p10=v1 p01=v2 p11=v2
+    float v0[3]; float v1[3]; float v2[3];
+    uint32_t prim_id; uint32_t pad[2];
+};
+struct alignas(16) PmPatchRecord {    // 64 B
+    float p00[3]; float p10[3]; float p01[3]; float p11[3];
+    uint32_t prim_id; uint32_t flags; uint32_t pad[2];
+};
+struct alignas(16) PmSphereRecord {   // 80 B; object_from_render rows 0..2 (affine: row 3 == 0,0,0,1)
+    float ofr[12];
+    float radius, z_min, z_max, phi_max;
+    uint32_t prim_id; uint32_t flags; uint32_t pad[2];
+};
+static_assert(sizeof(PmTriRecord) == 48 && sizeof(PmPatchRecord) == 64 && sizeof(PmSphereRecord) == 80, "record sizes");
+
+#define PM_MAX_LEAF 4
+#define PM_LDS_STACK 12      // per-lane entries kept in LDS
+#define PM_SPILL_STACK 36    // per-lane overflow entries (private memory)

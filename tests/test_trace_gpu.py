@@ -1,0 +1,179 @@
+"""GPU parity: batched closest-hit / any-hit through the C ABI vs the CPU oracle.
+
+Bar (BASELINE.json north_star): primitive ids bit-exact outside documented epsilon ties, t within 1e-5
+relative.  The leaf tests are op-for-op restatements, so these tests demand MORE: ids, t, u, v bit-identical
+for patches/triangles; for spheres ids and t bit-identical and (u,v) within 1e-5 (acos/atan2 come from
+different libms: glibc vs ROCm OCML).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MISS = 0xFFFFFFFF
+
+
+def _main_rs_geometry():
+    """the four primitives of src/main.rs:114-215 in render space (camera at (3,4,1.5) => render = world - cam)"""
+    cam = np.array([3.0, 4.0, 1.5], np.float32)
+
+    def translate(v):
+        m = np.eye(4, dtype=np.float32)
+        m[:3, 3] = np.asarray(v, np.float32) - cam
+        mi = np.eye(4, dtype=np.float32)
+        mi[:3, 3] = -(np.asarray(v, np.float32) - cam)
+        return m, mi
+
+    spheres = [(1.0, (0, 0, 0)), (1.5, (-3.5, -2.0, 0.5)), (0.75, (-0.3, -3.0, -0.25))]
+    floor = np.array([[-20, -20, 0], [20, -20, 0], [-20, 20, 0], [20, 20, 0]], np.float32) + (np.array([0, 0, -1], np.float32) - cam)
+    return spheres, translate, floor
+
+
+def _build_both(pm, ora, prims_spec):
+    """prims_spec: list of ('sphere', r, m, mi) | ('patch', pos, idx) | ('tri', pos, idx), in insertion order"""
+    prims = []
+    sc = ora.Scene()
+    for p in prims_spec:
+        if p[0] == "sphere":
+            _, r, m, mi = p
+            prims.append(pm.Sphere(r, -r, r, 360.0, m, mi))
+            sc.add_sphere(r, -r, r, 360.0, m, mi)
+        elif p[0] == "patch":
+            prims.append(pm.BilinearPatchMesh(p[1], p[2]))
+            sc.add_patch_mesh(p[1], p[2])
+        else:
+            prims.append(pm.TriangleMesh(p[1], p[2]))
+            sc.add_triangle_mesh(p[1], p[2])
+    agg = pm.GpuAggregate(prims)
+    sc.build(ora.SPLIT_MIDDLE, 255)
+    return agg, sc
+
+
+def _compare_closest(gpu, ref, sphere_ids=()):
+    assert np.array_equal(gpu["prim_id"], ref["prim_id"]), f"{(gpu['prim_id'] != ref['prim_id']).sum()} prim-id mismatches"
+    hit = ref["prim_id"] != MISS
+    assert np.array_equal(gpu["t"][hit].view(np.uint32), ref["t"][hit].view(np.uint32)), "t not bit-identical"
+    is_sph = np.isin(ref["prim_id"], np.asarray(sphere_ids, dtype=np.uint32)) & hit
+    flat = hit & ~is_sph
+    assert np.array_equal(gpu["u"][flat].view(np.uint32), ref["u"][flat].view(np.uint32))
+    assert np.array_equal(gpu["v"][flat].view(np.uint32), ref["v"][flat].view(np.uint32))
+    if is_sph.any():
+        np.testing.assert_allclose(gpu["u"][is_sph], ref["u"][is_sph], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(gpu["v"][is_sph], ref["v"][is_sph], rtol=1e-5, atol=1e-6)
+
+
+def test_triangle_soup_closest_and_any(pm, ora):
+    pos, idx = pm.scenes.blob_mesh(64, 256, seed=1)
+    agg, sc = _build_both(pm, ora, [("tri", pos, idx)])
+    rays = pm.scenes.primary_rays(256, 256)
+    ref, _ = sc.intersect(rays)
+    gpu = agg.intersect(rays)
+    assert (ref["prim_id"] != MISS).sum() > 1000
+    _compare_closest(gpu, ref)
+    inc = pm.scenes.incoherent_rays(100_000, seed=2)
+    ref_i, _ = sc.intersect(inc)
+    _compare_closest(agg.intersect(inc), ref_i)
+    sh = pm.scenes.shadow_rays(inc, ref_i)
+    ref_a, _ = sc.intersect_p(sh)
+    gpu_a = agg.intersect_p(sh)
+    assert ref_a.sum() > 100
+    assert np.array_equal(gpu_a, ref_a)
+
+
+def test_counters_match_cpu_walk_of_same_tree(pm, ora):
+    """pm_get_counters must reproduce the CPU walk of the GPU-layout tree exactly."""
+    pos, idx = pm.scenes.blob_mesh(32, 256, seed=5)
+    agg, sc = _build_both(pm, ora, [("tri", pos, idx)])
+    rays = pm.scenes.incoherent_rays(50_000, seed=9)
+    agg.set_counting(True)
+    agg.reset_counters()
+    gpu = agg.intersect(rays)
+    c = agg.counters()
+    cpu, cw = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays)
+    assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32))
+    assert c["rays"] == len(rays)
+    assert c["nodes_visited"] == cw["nodes_visited"]
+    assert c["prims_tested"] == cw["prims_tested"]
+    assert c["stack_overflows"] == 0
+    agg.reset_counters()
+    sh = pm.scenes.shadow_rays(rays, gpu)
+    ga = agg.intersect_p(sh)
+    ca, cwa = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), sh, any_hit=True)
+    c = agg.counters()
+    assert np.array_equal(ga, ca)
+    assert (c["nodes_visited"], c["prims_tested"]) == (cwa["nodes_visited"], cwa["prims_tested"])
+    agg.set_counting(False)
+
+
+def test_main_rs_scene_spheres_and_patch(pm, ora):
+    """C1 geometry (3 spheres + floor quad, insertion order of main.rs:217-219) seen from the camera."""
+    spheres, translate, floor = _main_rs_geometry()
+    spec = []
+    m, mi = translate(spheres[0][1])
+    spec.append(("sphere", spheres[0][0], m, mi))
+    spec.append(("patch", floor, np.array([[0, 1, 2, 3]], np.uint32)))
+    for r, c in spheres[1:]:
+        m, mi = translate(c)
+        spec.append(("sphere", r, m, mi))
+    agg, sc = _build_both(pm, ora, spec)
+    # camera rays: look from the origin of render space towards the scene, plus random incoherent rays inside it
+    rng = np.random.default_rng(3)
+    n = 200_000
+    rays = np.zeros(n, pm.RAY_DTYPE)
+    target = rng.uniform([-8, -9, -3], [0, 0, 1], size=(n, 3)).astype(np.float32)
+    d = target / np.linalg.norm(target, axis=1, keepdims=True)
+    rays["d"] = d.astype(np.float32)
+    rays["tmax"] = np.inf
+    # second half: rays starting on/inside the geometry (exercises t0 <= 0 branches and self-intersection epsilons)
+    rays["o"][n // 2:] = rng.uniform([-7, -8, -2.5], [-1, -2, 1], size=(n - n // 2, 3)).astype(np.float32)
+    rays["d"][n // 2:] = rng.normal(size=(n - n // 2, 3)).astype(np.float32)
+    ref, _ = sc.intersect(rays)
+    gpu = agg.intersect(rays)
+    ids = set(np.unique(ref["prim_id"]).tolist())
+    assert {0, 1, 2, 3} <= ids, ids
+    _compare_closest(gpu, ref, sphere_ids=(0, 2, 3))
+    sh = rays.copy()
+    sh["tmax"] = 5.0
+    ref_a, _ = sc.intersect_p(sh)
+    assert np.array_equal(agg.intersect_p(sh), ref_a)
+
+
+def test_edge_cases(pm, ora):
+    pos, idx = pm.scenes.blob_mesh(4, 64, seed=7)
+    agg, sc = _build_both(pm, ora, [("tri", pos, idx)])
+    # empty batch
+    assert len(agg.intersect(np.zeros(0, pm.RAY_DTYPE))) == 0
+    assert len(agg.intersect_p(np.zeros(0, pm.RAY_DTYPE))) == 0
+    # ragged batch (not a multiple of the block), axis-aligned and zero-component directions, tmax = 0, NaN-producing rays
+    rays = pm.scenes.incoherent_rays(1000 + 37, seed=11)
+    rays["d"][:100, 0] = 0.0
+    rays["d"][100:200, 1] = 0.0
+    rays["d"][200:220] = [0, 0, 1]
+    rays["tmax"][300:320] = 0.0
+    rays["tmax"][320:340] = 1e-3
+    rays["o"][340:360] = pos[:20]            # origins exactly on vertices
+    ref, _ = sc.intersect(rays)
+    _compare_closest(agg.intersect(rays), ref)
+    ref_a, _ = sc.intersect_p(rays)
+    assert np.array_equal(agg.intersect_p(rays), ref_a)
+    # a single primitive
+    one, sc1 = _build_both(pm, ora, [("tri", pos[:3], np.array([[0, 1, 2]], np.uint32))])
+    r1 = pm.scenes.incoherent_rays(4096, seed=1)
+    ref1, _ = sc1.intersect(r1)
+    _compare_closest(one.intersect(r1), ref1)
+
+
+def test_device_pointers_in_place(pm, ora):
+    """rays/hits already resident in HBM (torch tensors) are used without a copy."""
+    import torch
+    pos, idx = pm.scenes.blob_mesh(16, 256, seed=2)
+    agg, sc = _build_both(pm, ora, [("tri", pos, idx)])
+    rays = pm.scenes.incoherent_rays(65_536, seed=4)
+    d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
+    d_hits = torch.empty((len(rays), 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    agg.intersect(d_rays, out=d_hits)
+    gpu = d_hits.cpu().numpy().view(pm.HIT_DTYPE).reshape(-1)
+    ref, _ = sc.intersect(rays)
+    _compare_closest(gpu, ref)
+    assert agg.last_kernel_ms() > 0.0
