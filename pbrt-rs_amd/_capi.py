@@ -65,6 +65,13 @@ def load_library(path=LIB_PATH):
         raise ImportError(
             f"{path} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C pbrt-rs_amd/csrc).  There is no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; two HIP runtimes in one process do not coexist
+    # ("No HIP GPUs are available" from whichever initialises second).  Loading torch first makes the
+    # dynamic loader bind this library to the same runtime torch uses.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol

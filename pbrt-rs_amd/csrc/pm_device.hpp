@@ -236,7 +236,9 @@ PMD bool traverse(const PmWideNode* __restrict__ nodes, const uint4* __restrict_
     // holding only the root (index 0).
     uint2 cur = make_uint2(0u, (1u << 8) | perm8(1u, oct));
 
-    for (;;) {
+    // every lane leaves this loop: the tree is finite, and `guard` bounds the walk even if a buffer is corrupt
+    for (uint32_t guard = 0; guard < (1u << 22); ++guard) {
+        if (ANY && found) break;
         uint32_t pm = cur.y & 0xFFu;
         if (pm == 0u) {
             if (sp == 0) break;
@@ -290,13 +292,13 @@ PMD bool traverse(const PmWideNode* __restrict__ nodes, const uint4* __restrict_
         uint32_t lm = perm8(hits & ~imask, oct);
         const uint32_t ptype = n1.y >> 30;
         const uint32_t pbase = n1.y & 0x3FFFFFFFu;
-        while (lm) {
+        while (lm && !(ANY && found)) {
             const uint32_t kl = __ffs(lm) - 1u;
             lm &= lm - 1u;
             const uint32_t ls = kl ^ oct;
             const uint32_t meta = (metaw[ls >> 2] >> (8 * (ls & 3))) & 0xFFu;
             const uint32_t cnt = meta >> 5, off = meta & 31u;
-            for (uint32_t j = 0; j < cnt; ++j) {
+            for (uint32_t j = 0; j < cnt && !(ANY && found); ++j) {
                 if (COUNT) ctr->prims++;
                 if (ptype == PM_PRIM_TRI) {
                     const uint4* r = prims + pbase + (off + j) * PM_UNITS_TRI;
@@ -306,7 +308,6 @@ PMD bool traverse(const PmWideNode* __restrict__ nodes, const uint4* __restrict_
                     f3 v2 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
                     float t, u, v;
                     if (intersect_patch(ray.o, ray.d, tmax, v0, v1, v2, v2, &t, &u, &v)) {
-                        if (ANY) return true;
                         tmax = t; found = true; hit->prim_id = r2.y; hit->t = t; hit->u = u; hit->v = v;
                     }
                 } else if (ptype == PM_PRIM_PATCH) {
@@ -318,7 +319,6 @@ PMD bool traverse(const PmWideNode* __restrict__ nodes, const uint4* __restrict_
                     f3 p11 = mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
                     float t, u, v;
                     if (intersect_patch(ray.o, ray.d, tmax, p00, p10, p01, p11, &t, &u, &v)) {
-                        if (ANY) return true;
                         tmax = t; found = true; hit->prim_id = r3.x; hit->t = t; hit->u = u; hit->v = v;
                     }
                 } else {
@@ -332,7 +332,6 @@ PMD bool traverse(const PmWideNode* __restrict__ nodes, const uint4* __restrict_
                                 phimax = __uint_as_float(r3.w);
                     SphereHit sh;
                     if (intersect_sphere(ray.o, ray.d, tmax, m, radius, zmin, zmax, phimax, &sh)) {
-                        if (ANY) return true;
                         tmax = sh.t; found = true; hit->prim_id = r4.x; hit->t = sh.t;
                         // (u,v) of sphere.rs:382-385
                         const float th0 = acosf(fminf(fmaxf(zmin / radius, -1.0f), 1.0f));
