@@ -112,6 +112,93 @@ int pm_last_kernel_ms(pm_ctx* ctx, float* ms);
 int pm_get_node_buffer(pm_ctx* ctx, void* data, uint64_t cap, uint64_t* needed);
 int pm_get_prim_buffer(pm_ctx* ctx, void* data, uint64_t cap, uint64_t* needed);
 
+
+/* ============================================================================================
+ * Integrate::render() (integrators/base.rs:32-45,82-219; integrators/simple_path.rs:105-269)
+ * The host (scene_parsing / camera / lights / materials of the reference) flattens what it built
+ * into the structs below; the library runs the wavefront pipeline
+ *   raygen -> [closest-hit -> shade (+NEE ray) -> any-hit shadow] x depth -> accumulate
+ * and keeps the f64 film (camera/film.rs:302-307) in HBM.
+ * ============================================================================================ */
+
+/* sampling/spectrum.rs SpectrumEnum, evaluated exactly as the reference evaluates each variant.
+ * `table` = 471 floats for integer wavelengths 360..830 nm (DenselySampledSpectrum::at, :225-239). */
+enum { PM_SPEC_CONSTANT = 0,        /* a = c                                   (:163-186) */
+       PM_SPEC_DENSE = 1,           /* table                                   (:188-244) */
+       PM_SPEC_RGB_ALBEDO = 2,      /* sigmoid(c0=a,c1=b,c2=c)                 (:922-948) */
+       PM_SPEC_RGB_UNBOUNDED = 3,   /* d * sigmoid(a,b,c)                      (:950-979) */
+       PM_SPEC_RGB_ILLUMINANT = 4,  /* d * sigmoid(a,b,c) * table (illuminant) (:981-1019) */
+       PM_SPEC_BLACKBODY = 5 };     /* a = T [K], b = normalisation factor     (:376-437) */
+typedef struct PmSpectrum { int32_t kind; float a, b, c, d; const float* table; } PmSpectrum;
+
+/* materials/material.rs:111-201 (constant textures only, as in the reference) */
+enum { PM_MAT_DIFFUSE = 0, PM_MAT_DIELECTRIC = 1 };
+typedef struct PmMaterial {
+    int32_t type;
+    PmSpectrum spectrum;             /* DIFFUSE: reflectance; DIELECTRIC: eta */
+    float u_roughness, v_roughness;  /* DIELECTRIC */
+    int32_t remap_roughness;
+} PmMaterial;
+
+/* lights/{point,directional,infinite}.rs; `spectrum` is the light's DenselySampledSpectrum (471 floats) */
+enum { PM_LIGHT_POINT = 0, PM_LIGHT_DIRECTIONAL = 1, PM_LIGHT_UNIFORM_INFINITE = 2 };
+typedef struct PmLight { int32_t type; float scale; float render_from_light[16]; const float* spectrum; } PmLight;
+
+/* camera/perspective.rs:20-25 + camera/base.rs:260-327: the two matrices generate_ray uses */
+typedef struct PmCamera {
+    float camera_from_raster[16];
+    float render_from_camera[16];
+    float lens_radius, focal_distance;
+} PmCamera;
+
+/* camera/film.rs:108-121 RGBFilm + camera/sensor.rs:14-20 PixelSensor + imaging/filter.rs */
+enum { PM_FILTER_BOX = 0, PM_FILTER_TRIANGLE = 1, PM_FILTER_GAUSSIAN = 2 };
+typedef struct PmFilm {
+    int32_t full_resolution[2];
+    int32_t pixel_bounds[4];             /* x0, y0, x1, y1 */
+    float max_component_value, imaging_ratio;
+    float output_rgb_from_sensor_rgb[9];
+    const float* sensor_rgb_bar;         /* r_bar, g_bar, b_bar: 3 x 471 floats */
+    int32_t filter_kind; float filter_radius[2];
+    int32_t filter_nx, filter_ny;        /* GAUSSIAN: FilterSampler table (imaging/filter.rs:187-216), row-major */
+    const float* filter_vals;
+} PmFilm;
+
+enum { PM_INTEGRATOR_SIMPLE_PATH = 0, PM_INTEGRATOR_RANDOM_WALK = 1 };
+typedef struct PmRenderParams {
+    int32_t integrator, max_depth, sample_lights, sample_bsdf;
+    int32_t spp;              /* sampler.samples_per_pixel() */
+    uint32_t seed;            /* IndependentSampler seed (sampler.rs:77: None -> 0) */
+    int32_t window[4];        /* pixel window x0,y0,x1,y1 inside pixel_bounds (tile split across GPUs) */
+    int32_t s0, s1;           /* sample-index window [s0,s1) (sample split across GPUs) */
+} PmRenderParams;
+
+typedef struct PmRenderStats {
+    uint64_t samples, closest_rays, shadow_rays;
+    uint64_t passes, kernels_launched;
+    double kernel_ms;          /* device time of all kernels of the last pm_render (HIP events) */
+    double state_bytes_per_path;
+} PmRenderStats;
+
+int pm_set_materials(pm_ctx* ctx, const PmMaterial* mats, uint32_t n);
+int pm_set_prim_materials(pm_ctx* ctx, const uint32_t* material_id_per_prim, uint32_t n);
+int pm_set_lights(pm_ctx* ctx, const PmLight* lights, uint32_t n);
+int pm_set_camera(pm_ctx* ctx, const PmCamera* cam);
+int pm_set_film(pm_ctx* ctx, const PmFilm* film);           /* (re)allocates and clears the film */
+/* Integrate::render() restricted to a pixel/sample window; accumulates into the film in sample-index order */
+int pm_render(pm_ctx* ctx, const PmRenderParams* params);
+int pm_film_clear(pm_ctx* ctx);
+/* RGBPixel{rgb_sum[3], weight_sum} as 4 doubles per pixel, row-major over pixel_bounds; host or device pointer */
+int pm_film_read(pm_ctx* ctx, double* rgbw);
+/* film += rgbw (merging partial films from other GPUs: sample split) */
+int pm_film_add(pm_ctx* ctx, const double* rgbw);
+/* RGBFilm::get_pixel_rgb for every pixel (camera/film.rs:261-279): 3 floats per pixel */
+int pm_film_image(pm_ctx* ctx, float* rgb);
+int pm_get_render_stats(pm_ctx* ctx, PmRenderStats* out);
+/* test hook: unweighted radiance L[4] + lambda[4] + pdf[4] + filter weight of ONE (pixel, sample), recomputed
+ * on the device with the same kernels (13 floats) */
+int pm_debug_sample(pm_ctx* ctx, const PmRenderParams* params, int32_t px, int32_t py, int32_t sample_index, float* out13);
+
 #ifdef __cplusplus
 }
 #endif

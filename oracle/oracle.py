@@ -126,3 +126,61 @@ def wide_trace(node_buf, prim_buf, rays, any_hit=False, nthreads=8):
     lib().ora_wide_trace(node_buf.ctypes.data, prim_buf.ctypes.data, rays.ctypes.data, len(rays), out.ctypes.data,
                          int(any_hit), ctr.ctypes.data, nthreads)
     return out, {"nodes_visited": int(ctr[0]), "prims_tested": int(ctr[1])}
+
+
+class Renderer:
+    """Integrate::render() on the CPU.  Takes the flattened scene as ctypes objects laid out like the C-ABI
+    structs of include/pbrt_mi355.h (the oracle re-declares the layouts in ref_integrator.h)."""
+
+    def __init__(self, scene, materials, n_materials, prim_materials, lights, n_lights, camera, film):
+        L = lib()
+        p, u32 = C.c_void_p, C.c_uint32
+        L.ora_renderer_create.restype = p
+        L.ora_renderer_create.argtypes = [p, p, u32, p, u32, p, u32, p, p]
+        L.ora_renderer_destroy.argtypes = [p]
+        L.ora_renderer_render.argtypes = [p, p, C.c_int, p]
+        L.ora_renderer_clear.argtypes = [p]
+        L.ora_renderer_film.argtypes = [p, p]
+        L.ora_renderer_image.argtypes = [p, p]
+        L.ora_renderer_scene_radius.restype = C.c_float
+        L.ora_renderer_scene_radius.argtypes = [p]
+        L.ora_renderer_sample.argtypes = [p, p, C.c_int, C.c_int, C.c_int, p]
+        self._l = L
+        self._scene = scene
+        pm = np.ascontiguousarray(prim_materials, dtype=np.uint32)
+        self._h = C.c_void_p(L.ora_renderer_create(scene._h, C.addressof(materials), n_materials, pm.ctypes.data, len(pm),
+                                                   C.addressof(lights), n_lights, C.addressof(camera), C.addressof(film)))
+        b = film.pixel_bounds
+        self.width, self.height = b[2] - b[0], b[3] - b[1]
+
+    def render(self, params, nthreads=8):
+        ctr = np.zeros(4, np.uint64)
+        self._l.ora_renderer_render(self._h, C.addressof(params), nthreads, ctr.ctypes.data)
+        return {"samples": int(ctr[0]), "closest_rays": int(ctr[1]), "shadow_rays": int(ctr[2]), "bounces": int(ctr[3])}
+
+    def clear(self):
+        self._l.ora_renderer_clear(self._h)
+
+    def film(self):
+        out = np.empty((self.height, self.width, 4), np.float64)
+        self._l.ora_renderer_film(self._h, out.ctypes.data)
+        return out
+
+    def image(self):
+        out = np.empty((self.height, self.width, 3), np.float32)
+        self._l.ora_renderer_image(self._h, out.ctypes.data)
+        return out
+
+    def scene_radius(self):
+        return float(self._l.ora_renderer_scene_radius(self._h))
+
+    def sample(self, params, px, py, sample_index):
+        out = np.zeros(13, np.float32)
+        self._l.ora_renderer_sample(self._h, C.addressof(params), px, py, sample_index, out.ctypes.data)
+        return out
+
+    def __del__(self):
+        try:
+            self._l.ora_renderer_destroy(self._h)
+        except Exception:
+            pass

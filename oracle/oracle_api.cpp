@@ -4,6 +4,7 @@
 #include <atomic>
 #include <thread>
 
+#include "ref_integrator.h"
 #include "ref_render.h"
 #include "ref_scene.h"
 #include "wide_walk.h"
@@ -155,6 +156,56 @@ void ora_wide_trace(const void* nodes, const void* prims, const OraRay* rays, ui
         for (auto& c : ctr) { counters2[0] += c.nodes_visited; counters2[1] += c.prims_tested; }
     }
 }
+
+// ---- Integrate::render() on the CPU, from the flattened scene (same struct layouts as include/pbrt_mi355.h) ----
+struct OraRenderer {
+    Renderer r;
+    std::vector<std::vector<float>> tables;   // owned copies of every table the description points to
+    const float* own(const float* p, size_t n) { tables.emplace_back(p, p + n); return tables.back().data(); }
+};
+OraRenderer* ora_renderer_create(OraScene* s, const OMaterial* mats, uint32_t n_mats, const uint32_t* prim_mat, uint32_t n_prims,
+                                 const OLight* lights, uint32_t n_lights, const OCamera* cam, const OFilm* film) {
+    OraRenderer* o = new OraRenderer();
+    o->tables.reserve(n_mats + n_lights + 8);
+    o->r.scene = &s->sc;
+    o->r.materials.assign(mats, mats + n_mats);
+    for (auto& m : o->r.materials) if (m.spec.table) m.spec.table = o->own(m.spec.table, 471);
+    o->r.prim_material.assign(prim_mat, prim_mat + n_prims);
+    o->r.lights.assign(lights, lights + n_lights);
+    for (auto& l : o->r.lights) l.spectrum = o->own(l.spectrum, 471);
+    o->r.cam = *cam;
+    o->r.film = *film;
+    o->r.film.sensor_bar = o->own(film->sensor_bar, 3 * 471);
+    if (film->filter_vals) o->r.film.filter_vals = o->own(film->filter_vals, (size_t)film->filter_nx * film->filter_ny);
+    o->r.prepare();
+    return o;
+}
+void ora_renderer_destroy(OraRenderer* o) { delete o; }
+void ora_renderer_render(OraRenderer* o, const ORender* rp, int nthreads, uint64_t* counters4) {
+    RenderCounters rc = o->r.render(*rp, nthreads);
+    if (counters4) { counters4[0] = rc.samples; counters4[1] = rc.closest_rays; counters4[2] = rc.shadow_rays; counters4[3] = rc.bounces; }
+}
+void ora_renderer_clear(OraRenderer* o) { std::fill(o->r.pixels.begin(), o->r.pixels.end(), 0.0); }
+void ora_renderer_film(OraRenderer* o, double* rgbw) { std::memcpy(rgbw, o->r.pixels.data(), o->r.pixels.size() * sizeof(double)); }
+void ora_renderer_image(OraRenderer* o, float* rgb) { o->r.get_image(rgb); }
+float ora_renderer_scene_radius(OraRenderer* o) { return o->r.scene_radius; }
+// L[4], lambda[4], pdf[4], filter weight of one (pixel, sample) — no film add
+void ora_renderer_sample(OraRenderer* o, const ORender* rp, int px, int py, int sample_index, float* out13) {
+    RenderCounters rc; Spec4 L; Wavelengths w; float fw;
+    o->r.eval_pixel_sample(px, py, sample_index, *rp, &rc, &L, &w, &fw);
+    for (int i = 0; i < 4; ++i) { out13[i] = L.v[i]; out13[4 + i] = w.lambda[i]; out13[8 + i] = w.pdf[i]; }
+    out13[12] = fw;
+}
+// PixelSensor::to_sensor_rgb probe (camera/sensor.rs:114-121) for the golden vectors
+void ora_to_sensor_rgb(const float* sensor_bar3x471, float imaging_ratio, const float* L4, const float* lambda4, const float* pdf4, float* rgb3) {
+    for (int c = 0; c < 3; ++c) {
+        float sum = 0.0f;
+        for (int i = 0; i < 4; ++i) { float lp = pdf4[i] != 0.0f ? L4[i] / pdf4[i] : 0.0f; sum += dense_at(sensor_bar3x471 + 471 * c, lambda4[i]) * lp; }
+        rgb3[c] = sum / 4.0f * imaging_ratio;
+    }
+}
+float ora_dense_at(const float* table471, float lambda) { return dense_at(table471, lambda); }
+float ora_sigmoid_poly(float c0, float c1, float c2, float lambda) { return sigmoid_poly(c0, c1, c2, lambda); }
 
 // ---- single-function probes used by the golden-vector tests -----------------------------------
 float ora_next_float_up(float v) { return next_float_up(v); }

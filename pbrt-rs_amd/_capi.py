@@ -38,7 +38,53 @@ class PmCounters(C.Structure):
                 ("stack_overflows", C.c_uint64)]
 
 
-# every symbol include/pbrt_mi355.h declares: name -> (restype, argtypes)
+class PmSpectrum(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("a", C.c_float), ("b", C.c_float), ("c", C.c_float), ("d", C.c_float),
+                ("table", C.POINTER(C.c_float))]
+
+
+class PmMaterial(C.Structure):
+    _fields_ = [("type", C.c_int32), ("spectrum", PmSpectrum), ("u_roughness", C.c_float), ("v_roughness", C.c_float),
+                ("remap_roughness", C.c_int32)]
+
+
+class PmLight(C.Structure):
+    _fields_ = [("type", C.c_int32), ("scale", C.c_float), ("render_from_light", C.c_float * 16),
+                ("spectrum", C.POINTER(C.c_float))]
+
+
+class PmCamera(C.Structure):
+    _fields_ = [("camera_from_raster", C.c_float * 16), ("render_from_camera", C.c_float * 16),
+                ("lens_radius", C.c_float), ("focal_distance", C.c_float)]
+
+
+class PmFilm(C.Structure):
+    _fields_ = [("full_resolution", C.c_int32 * 2), ("pixel_bounds", C.c_int32 * 4),
+                ("max_component_value", C.c_float), ("imaging_ratio", C.c_float),
+                ("output_rgb_from_sensor_rgb", C.c_float * 9), ("sensor_rgb_bar", C.POINTER(C.c_float)),
+                ("filter_kind", C.c_int32), ("filter_radius", C.c_float * 2),
+                ("filter_nx", C.c_int32), ("filter_ny", C.c_int32), ("filter_vals", C.POINTER(C.c_float))]
+
+
+class PmRenderParams(C.Structure):
+    _fields_ = [("integrator", C.c_int32), ("max_depth", C.c_int32), ("sample_lights", C.c_int32),
+                ("sample_bsdf", C.c_int32), ("spp", C.c_int32), ("seed", C.c_uint32), ("window", C.c_int32 * 4),
+                ("s0", C.c_int32), ("s1", C.c_int32)]
+
+
+class PmRenderStats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("passes", C.c_uint64), ("kernels_launched", C.c_uint64), ("kernel_ms", C.c_double),
+                ("state_bytes_per_path", C.c_double)]
+
+
+PM_SPEC_CONSTANT, PM_SPEC_DENSE, PM_SPEC_RGB_ALBEDO, PM_SPEC_RGB_UNBOUNDED, PM_SPEC_RGB_ILLUMINANT, PM_SPEC_BLACKBODY = range(6)
+PM_MAT_DIFFUSE, PM_MAT_DIELECTRIC = 0, 1
+PM_LIGHT_POINT, PM_LIGHT_DIRECTIONAL, PM_LIGHT_UNIFORM_INFINITE = 0, 1, 2
+PM_FILTER_BOX, PM_FILTER_TRIANGLE, PM_FILTER_GAUSSIAN = 0, 1, 2
+PM_INTEGRATOR_SIMPLE_PATH, PM_INTEGRATOR_RANDOM_WALK = 0, 1
+
+# every symbol include/pbrt_mi355.h and include/pbrt_mi355_host.h declare: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
     "pm_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
@@ -57,6 +103,34 @@ SYMBOLS = {
     "pm_last_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "pm_get_node_buffer": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "pm_get_prim_buffer": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "pm_set_materials": (C.c_int, [_P, C.POINTER(PmMaterial), C.c_uint32]),
+    "pm_set_prim_materials": (C.c_int, [_P, _P, C.c_uint32]),
+    "pm_set_lights": (C.c_int, [_P, C.POINTER(PmLight), C.c_uint32]),
+    "pm_set_camera": (C.c_int, [_P, C.POINTER(PmCamera)]),
+    "pm_set_film": (C.c_int, [_P, C.POINTER(PmFilm)]),
+    "pm_render": (C.c_int, [_P, C.POINTER(PmRenderParams)]),
+    "pm_film_clear": (C.c_int, [_P]),
+    "pm_film_read": (C.c_int, [_P, _P]),
+    "pm_film_add": (C.c_int, [_P, _P]),
+    "pm_film_image": (C.c_int, [_P, _P]),
+    "pm_get_render_stats": (C.c_int, [_P, C.POINTER(PmRenderStats)]),
+    "pm_debug_sample": (C.c_int, [_P, C.POINTER(PmRenderParams), C.c_int32, C.c_int32, C.c_int32, _P]),
+    # include/pbrt_mi355_host.h
+    "pmh_mat4_inverse": (C.c_int, [_P, _P]),
+    "pmh_mat4_mul": (None, [_P, _P, _P]),
+    "pmh_look_at": (C.c_int, [_P, _P, _P, _P, _P]),
+    "pmh_perspective_camera": (C.c_int, [_P, _P, C.c_float, _P, C.c_int, C.c_int, C.c_float, C.c_float,
+                                         C.POINTER(PmCamera), _P, _P]),
+    "pmh_gaussian_filter_table": (C.c_int, [C.c_float, C.c_float, C.c_float, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pmh_gaussian": (C.c_float, [C.c_float, C.c_float, C.c_float]),
+    "pmh_fast_exp": (C.c_float, [C.c_float]),
+    "pmh_d65_table": (None, [_P, _P, C.c_int, _P]),
+    "pmh_photometric": (C.c_float, [_P, _P]),
+    "pmh_blackbody_table": (C.c_float, [C.c_float, _P]),
+    "pmh_rgb_spectrum_table": (None, [_P, C.c_float, _P, _P]),
+    "pmh_sigmoid_poly": (C.c_float, [_P, C.c_float]),
+    "pmh_rgb_to_coeffs": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "pmh_srgb_matrices": (C.c_int, [_P, _P, _P, _P, _P, _P]),
 }
 
 

@@ -1,60 +1,7 @@
 // C ABI of libpbrt_mi355.so (include/pbrt_mi355.h): context, geometry upload, wide-BVH build,
 // batched closest-hit / any-hit kernels.  gfx950 only.
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <string>
-#include <vector>
-
-#include "../../include/pbrt_mi355.h"
-#include "pm_build.h"
+#include "pm_ctx.h"
 #include "pm_device.hpp"
-
-#define TRACE_BLOCK 128
-
-struct pm_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::string err;
-    pm::HostScene scene;
-    pm::Accel accel;
-    bool accel_valid = false;
-    int split_method = PM_SPLIT_SAH;
-    PmWideNode* d_nodes = nullptr;
-    uint4* d_prims = nullptr;
-    unsigned long long* d_counters = nullptr;   // rays, nodes, prims, overflow
-    bool counting = false;
-    uint64_t rays_counted = 0;
-    float last_ms = 0.0f;
-    // staging for host-pointer callers
-    void* d_stage_in = nullptr; size_t stage_in_cap = 0;
-    void* d_stage_out = nullptr; size_t stage_out_cap = 0;
-};
-
-static int fail(pm_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
-#define HIPCHK(c, call)                                                                              \
-    do {                                                                                             \
-        hipError_t e_ = (call);                                                                      \
-        if (e_ != hipSuccess) return fail(c, PM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-
-static bool is_device_ptr(const void* p) {
-    hipPointerAttribute_t a;
-    hipError_t e = hipPointerGetAttributes(&a, p);
-    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
-}
-static int ensure(pm_ctx* c, void** buf, size_t* cap, size_t need) {
-    if (*cap >= need) return PM_OK;
-    if (*buf) HIPCHK(c, hipFree(*buf));
-    *buf = nullptr; *cap = 0;
-    HIPCHK(c, hipMalloc(buf, need));
-    *cap = need;
-    return PM_OK;
-}
 
 // ------------------------------------------------------------------------------------------ kernels
 // XCD-aware block remap: hardware deals consecutive workgroups round-robin over the 8 XCDs (each with
@@ -127,6 +74,7 @@ extern "C" void pm_destroy(pm_ctx* c) {
     if (c->device < 0) { delete c; return; }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    pm_render_state_destroy(c);
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     if (c->d_prims) (void)hipFree(c->d_prims);
     if (c->d_counters) (void)hipFree(c->d_counters);

@@ -1,0 +1,373 @@
+// Host-side mirror of the reference constructors whose OUTPUT crosses the C ABI (include/pbrt_mi355_host.h).
+// In a real integration the Rust host computes these with its own code (camera/, imaging/filter.rs,
+// sampling/spectrum.rs, color/) and passes the results to pm_set_camera / pm_set_film / pm_set_lights;
+// this C++ restatement exists so that the C++/Python harnesses of this repository (tests, bench, examples)
+// can build the same scenes without a Rust toolchain.  f32 arithmetic in the reference's operation order.
+#include "../../include/pbrt_mi355_host.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct M4 { float m[4][4]; };
+struct Xf { M4 m, inv; };
+
+float dop(float a, float b, float c, float d) {   // math.rs:78-87
+    float cd = c * d;
+    return std::fmaf(a, b, -cd) + std::fmaf(-c, d, cd);
+}
+float ip3(float a0, float b0, float a1, float b1, float a2, float b2) { return a0 * b0 + (a1 * b1 + a2 * b2); }
+
+// SquareMatrix<4>::inverse, core/square_matrix.rs:196-262 (only .val of inner_product! is read)
+bool inverse(const M4& A, M4* out) {
+    const auto& m = A.m;
+    float s0 = dop(m[0][0], m[1][1], m[1][0], m[0][1]), s1 = dop(m[0][0], m[1][2], m[1][0], m[0][2]);
+    float s2 = dop(m[0][0], m[1][3], m[1][0], m[0][3]), s3 = dop(m[0][1], m[1][2], m[1][1], m[0][2]);
+    float s4 = dop(m[0][1], m[1][3], m[1][1], m[0][3]), s5 = dop(m[0][2], m[1][3], m[1][2], m[0][3]);
+    float c0 = dop(m[2][0], m[3][1], m[3][0], m[2][1]), c1 = dop(m[2][0], m[3][2], m[3][0], m[2][2]);
+    float c2 = dop(m[2][0], m[3][3], m[3][0], m[2][3]), c3 = dop(m[2][1], m[3][2], m[3][1], m[2][2]);
+    float c4 = dop(m[2][1], m[3][3], m[3][1], m[2][3]), c5 = dop(m[2][2], m[3][3], m[3][2], m[2][3]);
+    float det = s0 * c5 + (-s1 * c4 + (s2 * c3 + (s3 * c2 + (s5 * c0 + -s4 * c1))));
+    if (det == 0.0f) return false;
+    float s = 1.0f / det;
+    float r[4][4] = {
+        {s * ip3(m[1][1], c5, m[1][3], c3, -m[1][2], c4), s * ip3(-m[0][1], c5, m[0][2], c4, -m[0][3], c3),
+         s * ip3(m[3][1], s5, m[3][3], s3, -m[3][2], s4), s * ip3(-m[2][1], s5, m[2][2], s4, -m[2][3], s3)},
+        {s * ip3(-m[1][0], c5, m[1][2], c2, -m[1][3], c1), s * ip3(m[0][0], c5, m[0][3], c1, -m[0][2], c2),
+         s * ip3(-m[3][0], s5, m[3][2], s2, -m[3][3], s1), s * ip3(m[2][0], s5, m[2][3], s1, -m[2][2], s2)},
+        {s * ip3(m[1][0], c4, m[1][3], c0, -m[1][1], c2), s * ip3(-m[0][0], c4, m[0][1], c2, -m[0][3], c0),
+         s * ip3(m[3][0], s4, m[3][3], s0, -m[3][1], s2), s * ip3(-m[2][0], s4, m[2][1], s2, -m[2][3], s0)},
+        {s * ip3(-m[1][0], c3, m[1][1], c1, -m[1][2], c0), s * ip3(m[0][0], c3, m[0][2], c0, -m[0][1], c1),
+         s * ip3(-m[3][0], s3, m[3][1], s1, -m[3][2], s0), s * ip3(m[2][0], s3, m[2][2], s0, -m[2][1], s1)}};
+    std::memcpy(out->m, r, sizeof(r));
+    return true;
+}
+M4 matmul(const M4& a, const M4& b) {   // square_matrix.rs:316-332 (mul_add accumulation)
+    M4 r;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float acc = 0.0f;
+            for (int k = 0; k < 4; ++k) acc = std::fmaf(a.m[i][k], b.m[k][j], acc);
+            r.m[i][j] = acc;
+        }
+    return r;
+}
+Xf xmul(const Xf& a, const Xf& b) { return Xf{matmul(a.m, b.m), matmul(b.inv, a.inv)}; }   // transform.rs:312-317
+Xf xinv(const Xf& a) { return Xf{a.inv, a.m}; }
+M4 ident() { M4 r{}; for (int i = 0; i < 4; ++i) r.m[i][i] = 1.0f; return r; }
+Xf translate(float x, float y, float z) {   // transform.rs:60-75
+    Xf t{ident(), ident()};
+    t.m.m[0][3] = x; t.m.m[1][3] = y; t.m.m[2][3] = z;
+    t.inv.m[0][3] = -x; t.inv.m[1][3] = -y; t.inv.m[2][3] = -z;
+    return t;
+}
+Xf scale(float x, float y, float z) {       // transform.rs:78-93
+    Xf t{ident(), ident()};
+    t.m.m[0][0] = x; t.m.m[1][1] = y; t.m.m[2][2] = z;
+    t.inv.m[0][0] = 1.0f / x; t.inv.m[1][1] = 1.0f / y; t.inv.m[2][2] = 1.0f / z;
+    return t;
+}
+struct V { float x, y, z; };
+V vsub(V a, V b) { return V{a.x - b.x, a.y - b.y, a.z - b.z}; }
+V vcross(V a, V b) {
+    double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z;
+    return V{(float)(ay * bz - az * by), (float)(az * bx - ax * bz), (float)(ax * by - ay * bx)};
+}
+V vnorm(V a) { float l = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); return V{a.x / l, a.y / l, a.z / l}; }
+void put(const M4& m, float* o) { std::memcpy(o, m.m, 64); }
+M4 get(const float* p) { M4 m; std::memcpy(m.m, p, 64); return m; }
+
+float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+float eval_poly(float t, const float* c, int n) { float s = 0.0f; for (int i = n - 1; i >= 0; --i) s = std::fmaf(s, t, c[i]); return s; }
+int exponent(float v) { uint32_t u; std::memcpy(&u, &v, 4); return (int)((u & 0x7F800000u) >> 23) - 127; }
+float fast_exp(float x) {     // core/routines.rs:47-73
+    float xp = x * 1.44269504088896340736f;
+    float fxp = std::floor(xp), f = xp - fxp;
+    int i = (int)std::trunc(fxp);
+    const float c[4] = {1.0f, 0.6955569f, 0.22617356f, 0.07814557f};
+    float t = eval_poly(f, c, 4);
+    int e = exponent(t) + i;
+    if (e < -126) return 0.0f;
+    if (e > 127) return INFINITY;
+    uint32_t b; std::memcpy(&b, &t, 4);
+    b = (b & 0x807FFFFFu) | ((uint32_t)(e + 127) << 23);
+    float r; std::memcpy(&r, &b, 4);
+    return r;
+}
+float gaussian(float x, float mean, float sd) {   // math.rs:10-13
+    float d = x - mean;
+    return 1.0f / std::sqrt(2.0f * 3.14159265358979323846f * sd * sd) * fast_exp(-(d * d) / (2.0f * sd * sd));
+}
+float sigmoid_poly(const float* c, float lambda) {   // color_space.rs:243-280
+    const float p[3] = {c[2], c[1], c[0]};
+    float x = eval_poly(lambda, p, 3);
+    if (std::isinf(x)) return x > 0.0f ? 1.0f : 0.0f;
+    return 0.5f + x / (2.0f * std::sqrt(1.0f + x * x));
+}
+
+}  // namespace
+
+extern "C" {
+
+int pmh_mat4_inverse(const float* m16, float* out16) {
+    M4 r;
+    if (!inverse(get(m16), &r)) return 1;
+    put(r, out16);
+    return 0;
+}
+void pmh_mat4_mul(const float* a16, const float* b16, float* out16) { put(matmul(get(a16), get(b16)), out16); }
+
+// Transform::look_at (core/transform.rs:207-223): out_m = camera_from_world, out_inv = world_from_camera
+int pmh_look_at(const float* pos, const float* look, const float* up, float* out_m, float* out_inv) {
+    V p{pos[0], pos[1], pos[2]}, l{look[0], look[1], look[2]}, u{up[0], up[1], up[2]};
+    V dir = vnorm(vsub(l, p));
+    V right = vnorm(vcross(vnorm(u), dir));
+    V nup = vcross(dir, right);
+    M4 c2w{{{right.x, nup.x, dir.x, p.x}, {right.y, nup.y, dir.y, p.y}, {right.z, nup.z, dir.z, p.z}, {0, 0, 0, 1}}};
+    M4 w2c;
+    if (!inverse(c2w, &w2c)) return 1;
+    put(w2c, out_m); put(c2w, out_inv);
+    return 0;
+}
+
+// CameraTransform::new (camera/base.rs:265-279) + PerspectiveCamera::new (camera/perspective.rs:30-57) +
+// ProjectiveCamera::new (camera/base.rs:342-380).  world_from_camera is given as (m, inverse).
+int pmh_perspective_camera(const float* wfc_m, const float* wfc_inv, float fov_deg, const float* screen_window4,
+                           int res_x, int res_y, float lens_radius, float focal_distance, PmCamera* out,
+                           float* world_from_render16, float* render_from_world16) {
+    Xf wfc{get(wfc_m), get(wfc_inv)};
+    // p_camera = world_from_camera * Point3f::ZERO
+    const auto& m = wfc.m.m;
+    float px = 0.0f * m[0][0] + 0.0f * m[0][1] + 0.0f * m[0][2] + m[0][3];
+    float py = 0.0f * m[1][0] + 0.0f * m[1][1] + 0.0f * m[1][2] + m[1][3];
+    float pz = 0.0f * m[2][0] + 0.0f * m[2][1] + 0.0f * m[2][2] + m[2][3];
+    Xf wfr = translate(px, py, pz);
+    Xf rfw = xinv(wfr);
+    Xf rfc = xmul(rfw, wfc);
+    // Transform::perspective(fov, 0.01, 1000.0) (core/transform.rs:236-255)
+    const float n = 0.01f, f = 1000.0f;
+    M4 persp{{{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, f / (f - n), -f * n / (f - n)}, {0, 0, 1, 0}}};
+    Xf pt; pt.m = persp;
+    if (!inverse(persp, &pt.inv)) return 1;
+    float inv_tan = 1.0f / std::tan(fov_deg * (3.14159265358979323846f / 180.0f) / 2.0f);
+    Xf sfc = xmul(scale(inv_tan, inv_tan, 1.0f), pt);
+    const float* sw = screen_window4;   // min.x, min.y, max.x, max.y
+    Xf ndc_from_screen = xmul(scale(1.0f / (sw[2] - sw[0]), 1.0f / (sw[3] - sw[1]), 1.0f), translate(-sw[0], -sw[3], 0.0f));
+    Xf raster_from_ndc = scale((float)res_x, -(float)res_y, 1.0f);
+    Xf raster_from_screen = xmul(raster_from_ndc, ndc_from_screen);
+    Xf screen_from_raster = xinv(raster_from_screen);
+    Xf cfr = xmul(xinv(sfc), screen_from_raster);
+    put(cfr.m, out->camera_from_raster);
+    put(rfc.m, out->render_from_camera);
+    out->lens_radius = lens_radius; out->focal_distance = focal_distance;
+    if (world_from_render16) put(wfr.m, world_from_render16);
+    if (render_from_world16) put(rfw.m, render_from_world16);
+    return 0;
+}
+
+// GaussianFilter::new + FilterSampler::new (imaging/filter.rs:138-216): tabulated filter, row-major [ny][nx].
+// Bounds2f::lerp (core/bounds.rs:948-953) interpolates BOTH coordinates between p_min.x and p_max.x.
+int pmh_gaussian_filter_table(float rx, float ry, float sigma, float* vals, int cap, int* nx_out, int* ny_out) {
+    int nx = (int)(32.0f * rx), ny = (int)(32.0f * ry);
+    *nx_out = nx; *ny_out = ny;
+    if (!vals) return 0;
+    if (cap < nx * ny) return 1;
+    float exp_x = gaussian(rx, 0.0f, sigma), exp_y = gaussian(ry, 0.0f, sigma);
+    float dmin = std::fmin(-rx, rx), dmax = std::fmax(-rx, rx);
+    for (int y = 0; y < ny; ++y)
+        for (int x = 0; x < nx; ++x) {
+            float tx = ((float)x + 0.5f) / (float)nx, ty = ((float)y + 0.5f) / (float)ny;
+            float p0 = lerpf(dmin, dmax, tx), p1 = lerpf(dmin, dmax, ty);
+            float gx = std::fmax(gaussian(p0, 0.0f, sigma) - exp_x, 0.0f);
+            float gy = std::fmax(gaussian(p1, 0.0f, sigma) - exp_y, 0.0f);
+            vals[y * nx + x] = gx * gy;
+        }
+    return 0;
+}
+float pmh_gaussian(float x, float mean, float sd) { return gaussian(x, mean, sd); }
+float pmh_fast_exp(float x) { return fast_exp(x); }
+
+// ILLUMD65 (sampling/spectrum.rs:64-65,269-310) densified at 360..830 (DenselySampledSpectrum::new, :196-214)
+void pmh_d65_table(const float* cie_y471, const float* d65_interleaved, int n_interleaved, float* out471) {
+    int n = n_interleaved / 2;
+    std::vector<float> lam, val;
+    if (d65_interleaved[0] > 360.0f) { lam.push_back(359.0f); val.push_back(d65_interleaved[1]); }
+    for (int i = 0; i < n; ++i) { lam.push_back(d65_interleaved[2 * i]); val.push_back(d65_interleaved[2 * i + 1]); }
+    if (lam.back() < 830.0f) { lam.push_back(831.0f); val.push_back(val.back()); }
+    auto at = [&](float l) {
+        if (l < lam.front() || l > lam.back()) return 0.0f;
+        int sz = (int)lam.size(), left = 0, right = sz - 1;     // find_interval(|i| lam[i] <= l)
+        while (left < right) { int mid = left + (right - left) / 2; if (lam[mid] <= l) left = mid + 1; else right = mid; }
+        int i = left == 0 ? 0 : (left >= sz - 1 ? sz - 2 : left - 1);
+        if (l == lam[i]) return val[i];
+        float t = (l - lam[i]) / (lam[i + 1] - lam[i]);
+        return lerpf(val[i], val[i + 1], t);
+    };
+    float integral = 0.0f;
+    for (int l = 360; l <= 830; ++l) integral += at((float)l) * cie_y471[l - 360];
+    float s = 106.856895f / integral;
+    for (auto& v : val) v *= s;
+    for (int l = 360; l <= 830; ++l) out471[l - 360] = at((float)l);
+}
+// Spectrum::to_photometric (sampling/spectrum.rs:152-160)
+float pmh_photometric(const float* cie_y471, const float* table471) {
+    float y = 0.0f;
+    for (int i = 0; i < 471; ++i) y += cie_y471[i] * table471[i];
+    return y;
+}
+// BlackbodySpectrum (sampling/spectrum.rs:376-437) densified; returns the normalisation factor
+float pmh_blackbody_table(float temp, float* out471) {
+    auto bb = [&](float lambda) {
+        if (temp <= 0.0f) return 0.0f;
+        const float C = 299792458.0f, H = 6.6260697e-34f, KB = 1.3806488e-23f;
+        float l = lambda * 1e-9f;
+        float l5 = ((l * l) * (l * l)) * l;
+        return (2.0f * H * C * C) / (l5 * (std::exp((H * C) / (l * KB * temp)) - 1.0f));
+    };
+    float lambda_max = 2.897772e-3f / temp;
+    float norm = 1.0f / bb(lambda_max * 1e9f);
+    for (int l = 360; l <= 830; ++l) out471[l - 360] = bb((float)l) * norm;
+    return norm;
+}
+// scale * sigmoid(c0,c1,c2)(lambda) [* illuminant(lambda)] densified (RgbAlbedo / RgbUnbounded / RgbIlluminant)
+void pmh_rgb_spectrum_table(const float* c3, float scale, const float* illuminant471_or_null, float* out471) {
+    for (int l = 360; l <= 830; ++l) {
+        float v = sigmoid_poly(c3, (float)l);
+        if (illuminant471_or_null) out471[l - 360] = scale * v * illuminant471_or_null[l - 360];
+        else out471[l - 360] = scale * v;
+    }
+}
+float pmh_sigmoid_poly(const float* c3, float lambda) { return sigmoid_poly(c3, lambda); }
+
+// RGB -> sigmoid-polynomial coefficients.  The reference looks these up (trilinearly) in a 3x64^3 table file that
+// is missing from the snapshot (util/data.rs:1684-1702, .MISSING_LARGE_BLOBS); this solves the same optimisation
+// problem the table generator solves (Jakob & Hanika 2019: Gauss-Newton on the CIELAB residual of the spectrum
+// sigmoid(c0 l^2 + c1 l + c2) under the colour space's illuminant) directly for one RGB.  Not bit-identical to a
+// table lookup (no interpolation error here); see DESIGN.md.
+int pmh_rgb_to_coeffs(const float* rgb3, const float* cie_x, const float* cie_y, const float* cie_z,
+                      const float* illuminant471, const float* xyz_from_rgb9, float* out_c3) {
+    double r = rgb3[0], g = rgb3[1], b = rgb3[2];
+    if (r == g && g == b) {   // color_space.rs:130-136
+        float x = rgb3[0];
+        out_c3[0] = 0.0f; out_c3[1] = 0.0f; out_c3[2] = (x - 0.5f) / std::sqrt(x * (1.0f - x));
+        return 0;
+    }
+    const int N = 471;
+    double rgb_from_xyz[9];
+    {   // 3x3 inverse
+        const float* m = xyz_from_rgb9;
+        double a = m[0], bb = m[1], c = m[2], d = m[3], e = m[4], f = m[5], gg = m[6], h = m[7], i = m[8];
+        double det = a * (e * i - f * h) - bb * (d * i - f * gg) + c * (d * h - e * gg);
+        if (det == 0) return 1;
+        double id = 1.0 / det;
+        double inv[9] = {(e * i - f * h) * id, (c * h - bb * i) * id, (bb * f - c * e) * id, (f * gg - d * i) * id, (a * i - c * gg) * id,
+                         (c * d - a * f) * id, (d * h - e * gg) * id, (bb * gg - a * h) * id, (a * e - bb * d) * id};
+        std::memcpy(rgb_from_xyz, inv, sizeof(inv));
+    }
+    // quadrature tables: rgb_tbl[c][i] = weight_i * I(l_i) * (rgb_from_xyz * xyz(l_i))[c], normalised so white -> (1,1,1)
+    std::vector<double> tbl(3 * N), lam(N);
+    double wp[3] = {0, 0, 0}, ynorm = 0;
+    for (int i = 0; i < N; ++i) {
+        double w = (i == 0 || i == N - 1) ? 0.5 : 1.0;   // trapezoid, 1 nm
+        double I = illuminant471[i];
+        double xyz[3] = {cie_x[i] * I * w, cie_y[i] * I * w, cie_z[i] * I * w};
+        ynorm += xyz[1];
+        for (int c = 0; c < 3; ++c) wp[c] += xyz[c];
+        for (int c = 0; c < 3; ++c) tbl[c * N + i] = rgb_from_xyz[c * 3 + 0] * xyz[0] + rgb_from_xyz[c * 3 + 1] * xyz[1] + rgb_from_xyz[c * 3 + 2] * xyz[2];
+        lam[i] = (double)i / (N - 1);
+    }
+    for (auto& v : tbl) v /= ynorm;
+    for (int c = 0; c < 3; ++c) wp[c] /= ynorm;
+    auto lab = [&](const double* rgbv, double* out) {
+        double xyz[3];
+        for (int k = 0; k < 3; ++k) xyz[k] = xyz_from_rgb9[k * 3] * rgbv[0] + xyz_from_rgb9[k * 3 + 1] * rgbv[1] + xyz_from_rgb9[k * 3 + 2] * rgbv[2];
+        auto f = [](double t) { const double d = 6.0 / 29.0; return t > d * d * d ? std::cbrt(t) : t / (3 * d * d) + 4.0 / 29.0; };
+        double fx = f(xyz[0] / wp[0]), fy = f(xyz[1] / wp[1]), fz = f(xyz[2] / wp[2]);
+        out[0] = 116 * fy - 16; out[1] = 500 * (fx - fy); out[2] = 200 * (fy - fz);
+    };
+    auto residual = [&](const double* co, double* res) {
+        double out[3] = {0, 0, 0};
+        for (int i = 0; i < N; ++i) {
+            double x = (co[0] * lam[i] + co[1]) * lam[i] + co[2];
+            double s = 0.5 + 0.5 * x / std::sqrt(1.0 + x * x);
+            for (int c = 0; c < 3; ++c) out[c] += tbl[c * N + i] * s;
+        }
+        double l0[3], l1[3];
+        const double target[3] = {r, g, b};
+        lab(target, l0); lab(out, l1);
+        for (int c = 0; c < 3; ++c) res[c] = l0[c] - l1[c];
+    };
+    double co[3] = {0, 0, 0};
+    for (int it = 0; it < 30; ++it) {
+        double res[3]; residual(co, res);
+        double J[3][3];
+        for (int k = 0; k < 3; ++k) {
+            double t[3] = {co[0], co[1], co[2]}, r0[3], r1[3];
+            const double eps = 1e-4;
+            t[k] = co[k] - eps; residual(t, r0);
+            t[k] = co[k] + eps; residual(t, r1);
+            for (int j = 0; j < 3; ++j) J[j][k] = (r1[j] - r0[j]) / (2 * eps);
+        }
+        // solve J x = res (Cramer)
+        double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                     J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+        if (std::fabs(det) < 1e-30) break;
+        double x[3];
+        for (int k = 0; k < 3; ++k) {
+            double M[3][3];
+            std::memcpy(M, J, sizeof(M));
+            for (int j = 0; j < 3; ++j) M[j][k] = res[j];
+            x[k] = (M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                    M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0])) / det;
+        }
+        double rr = 0;
+        for (int k = 0; k < 3; ++k) { co[k] -= x[k]; rr += res[k] * res[k]; }
+        double mx = std::fmax(std::fmax(std::fabs(co[0]), std::fabs(co[1])), std::fabs(co[2]));
+        if (mx > 200) for (int k = 0; k < 3; ++k) co[k] *= 200 / mx;
+        if (rr < 1e-12) break;
+    }
+    // from the normalised wavelength domain to nanometres
+    const double c0 = 360.0, c1 = 1.0 / (830.0 - 360.0);
+    double A = co[0], B = co[1], C = co[2];
+    out_c3[0] = (float)(A * c1 * c1);
+    out_c3[1] = (float)(B * c1 - 2 * A * c0 * c1 * c1);
+    out_c3[2] = (float)(C - B * c0 * c1 + A * (c0 * c1) * (c0 * c1));
+    return 0;
+}
+
+// RGBColorSpace::new for sRGB primaries (color/color_space.rs:40-89): xyz_from_rgb and rgb_from_xyz (f32)
+int pmh_srgb_matrices(const float* cie_x, const float* cie_y, const float* cie_z, const float* illuminant471,
+                      float* xyz_from_rgb9, float* rgb_from_xyz9) {
+    // W = illuminant.to_xyz() = (inner products) / CIE_Y_INTEGRAL
+    float X = 0, Y = 0, Z = 0;
+    for (int i = 0; i < 471; ++i) { X += illuminant471[i] * cie_x[i]; Y += illuminant471[i] * cie_y[i]; Z += illuminant471[i] * cie_z[i]; }
+    X /= 106.856895f; Y /= 106.856895f; Z /= 106.856895f;
+    auto from_xyy = [](float x, float y, float* o) {   // XYZ::from_xyy with Y = 1
+        if (y == 0.0f) { o[0] = o[1] = o[2] = 0.0f; return; }
+        o[0] = x * 1.0f / y; o[1] = 1.0f; o[2] = (1.0f - x - y) * 1.0f / y;
+    };
+    float R[3], G[3], B[3];
+    from_xyy(0.64f, 0.33f, R); from_xyy(0.3f, 0.6f, G); from_xyy(0.15f, 0.06f, B);
+    double m[9] = {R[0], G[0], B[0], R[1], G[1], B[1], R[2], G[2], B[2]};
+    double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    if (det == 0) return 1;
+    double id = 1.0 / det;
+    double inv[9] = {(m[4] * m[8] - m[5] * m[7]) * id, (m[2] * m[7] - m[1] * m[8]) * id, (m[1] * m[5] - m[2] * m[4]) * id,
+                     (m[5] * m[6] - m[3] * m[8]) * id, (m[0] * m[8] - m[2] * m[6]) * id, (m[2] * m[3] - m[0] * m[5]) * id,
+                     (m[3] * m[7] - m[4] * m[6]) * id, (m[1] * m[6] - m[0] * m[7]) * id, (m[0] * m[4] - m[1] * m[3]) * id};
+    double C[3] = {inv[0] * X + inv[1] * Y + inv[2] * Z, inv[3] * X + inv[4] * Y + inv[5] * Z, inv[6] * X + inv[7] * Y + inv[8] * Z};
+    double xr[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) xr[r * 3 + c] = m[r * 3 + c] * C[c];
+    double d2 = xr[0] * (xr[4] * xr[8] - xr[5] * xr[7]) - xr[1] * (xr[3] * xr[8] - xr[5] * xr[6]) + xr[2] * (xr[3] * xr[7] - xr[4] * xr[6]);
+    if (d2 == 0) return 1;
+    double i2 = 1.0 / d2;
+    double rx[9] = {(xr[4] * xr[8] - xr[5] * xr[7]) * i2, (xr[2] * xr[7] - xr[1] * xr[8]) * i2, (xr[1] * xr[5] - xr[2] * xr[4]) * i2,
+                    (xr[5] * xr[6] - xr[3] * xr[8]) * i2, (xr[0] * xr[8] - xr[2] * xr[6]) * i2, (xr[2] * xr[3] - xr[0] * xr[5]) * i2,
+                    (xr[3] * xr[7] - xr[4] * xr[6]) * i2, (xr[1] * xr[6] - xr[0] * xr[7]) * i2, (xr[0] * xr[4] - xr[1] * xr[3]) * i2};
+    for (int k = 0; k < 9; ++k) { xyz_from_rgb9[k] = (float)xr[k]; rgb_from_xyz9[k] = (float)rx[k]; }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,725 @@
+// Wavefront path tracer: Integrate::render() of the reference (integrators/base.rs:82-219,
+// integrators/simple_path.rs:105-269) as a pipeline of kernels over a pass of paths whose state lives in HBM:
+//
+//   raygen            one path per (pixel, sample index) of the pass: PCG32 stream, wavelengths, filter, camera ray
+//   closest_hit       BVHAggregate::intersect for the active queue
+//   shade             interaction + BSDF; miss -> infinite lights; NEE ray -> shadow queue; BSDF sample -> next queue
+//                     (queue compaction: wave ballot + LDS prefix over the block's waves, one atomic per block)
+//   shadow            BVHAggregate::intersect_p for the shadow queue; unoccluded -> L += contribution
+//   accumulate        per pixel, in sample-index order: PixelSensor::to_sensor_rgb + f64 film add (film.rs:160-192)
+//
+// One film add per (pixel, sample) in sample-index order => the f64 sums are bit-reproducible and equal to
+// the CPU's one-thread-per-pixel order, with no atomics.
+#include "pm_ctx.h"
+#include "pm_shade.hpp"
+
+#define RB 256          // block size of the non-traversal kernels
+#define TB TRACE_BLOCK  // block size of the traversal kernels
+
+using namespace pmd;
+
+struct PathArrays {
+    float4 *ray_o, *ray_d, *beta, *L, *lambda, *pdf, *hit, *sh_o, *sh_d, *sh_L;
+    uint4* rng;
+    uint2* misc;          // x: depth | specular << 8 ; y: filter weight bits
+    uint32_t *q0, *q1, *shq;
+    uint32_t* counts;     // [2 * (max_depth + 2)]: active count per bounce, shadow count per bounce
+};
+struct SceneArrays {
+    const PmWideNode* nodes; const uint4* prims;
+    const uint32_t* prim_ref;        // prim id -> type << 30 | index into shade arrays
+    const DShadePatch* patches; const DShadeSphere* spheres;
+    const uint32_t* prim_material; const DMaterial* materials; const DLight* lights; const int* infinite;
+    const float* pool;
+};
+
+__device__ __forceinline__ uint32_t xcd_remap_r(uint32_t b, uint32_t nb) {
+    const uint32_t q = nb >> 3, r = nb & 7u, x = b & 7u;
+    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (b >> 3);
+}
+__device__ __forceinline__ bool slot_pixel(const RenderConst& rc, uint32_t slot, int* px, int* py, int* s) {
+    const uint32_t p = slot % (uint32_t)rc.npix_pad;
+    *s = rc.s_base + (int)(slot / (uint32_t)rc.npix_pad);
+    const uint32_t tile = p >> 6, it = p & 63u;
+    const int x = (int)(tile % (uint32_t)rc.tiles_x) * 8 + (int)(it & 7u);
+    const int y = (int)(tile / (uint32_t)rc.tiles_x) * 8 + (int)(it >> 3);
+    *px = rc.win_x0 + x; *py = rc.win_y0 + y;
+    return x < rc.win_w && y < rc.win_h;
+}
+
+// ------------------------------------------------------------------------------------------ raygen
+__global__ __launch_bounds__(RB) void raygen_kernel(RenderConst rc, SceneArrays sc, PathArrays pa, uint32_t npaths) {
+    const uint32_t slot = blockIdx.x * RB + threadIdx.x;
+    if (slot >= npaths) return;
+    int px, py, s;
+    const bool inside = slot_pixel(rc, slot, &px, &py, &s);
+    pa.q0[slot] = slot;     // queue 0 is the identity; padded slots are retired by the first shade pass
+    if (slot == 0) pa.counts[0] = npaths;
+    if (!inside) {
+        pa.misc[slot] = make_uint2(0xFFFFFFFFu, 0u);
+        pa.L[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    Rng rng = rng_start(px, py, rc.seed, (unsigned long long)s, 0ull);
+    const float lu = rng_uniform(&rng);
+    float lam[4], pdf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float up = lu + (float)i / 4.0f;
+        if (up > 1.0f) up -= 1.0f;
+        lam[i] = sample_visible_wavelength(up);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pdf[i] = visible_pdf(lam[i]);
+    f2 uf; uf.x = rng_uniform(&rng); uf.y = rng_uniform(&rng);
+    f2 fp; float fw;
+    filter_sample(sc.pool, rc.filter, uf, &fp, &fw);
+    f2 pf; pf.x = (float)px + fp.x + 0.5f; pf.y = (float)py + fp.y + 0.5f;
+    (void)rng_uniform(&rng);    // time
+    f2 pl; pl.x = rng_uniform(&rng); pl.y = rng_uniform(&rng);
+    f3 o, d;
+    generate_camera_ray(rc, pf, pl, &o, &d);
+    pa.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.f);
+    pa.ray_d[slot] = make_float4(d.x, d.y, d.z, 0.f);
+    pa.beta[slot] = make_float4(1.f, 1.f, 1.f, 1.f);
+    pa.L[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    pa.lambda[slot] = make_float4(lam[0], lam[1], lam[2], lam[3]);
+    pa.pdf[slot] = make_float4(pdf[0], pdf[1], pdf[2], pdf[3]);
+    pa.rng[slot] = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), (uint32_t)rng.inc, (uint32_t)(rng.inc >> 32));
+    pa.misc[slot] = make_uint2(0u | (1u << 8), __float_as_uint(fw));   // depth 0, specular_bounce = true
+}
+
+// ------------------------------------------------------------------------------------------ traversal
+__global__ __launch_bounds__(TB) void closest_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
+                                                     const uint32_t* __restrict__ count) {
+    __shared__ uint2 stack[PM_LDS_STACK * TB];
+    const uint32_t i = xcd_remap_r(blockIdx.x, gridDim.x) * TB + threadIdx.x;
+    if (i >= *count) return;
+    const uint32_t slot = queue[i];
+    if (pa.misc[slot].x == 0xFFFFFFFFu) return;
+    const float4 o = pa.ray_o[slot], d = pa.ray_d[slot];
+    Ray ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(d.x, d.y, d.z); ray.tmax = INFINITY;
+    HitRec h; TravCounters tc = {0u, 0u, 0u};
+    traverse<false, false>(sc.nodes, sc.prims, ray, &h, stack + threadIdx.x, TB, &tc);
+    pa.hit[slot] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
+}
+__global__ __launch_bounds__(TB) void shadow_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ count) {
+    __shared__ uint2 stack[PM_LDS_STACK * TB];
+    const uint32_t i = xcd_remap_r(blockIdx.x, gridDim.x) * TB + threadIdx.x;
+    if (i >= *count) return;
+    const uint32_t slot = pa.shq[i];
+    const float4 o = pa.sh_o[slot], d = pa.sh_d[slot];
+    Ray ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(d.x, d.y, d.z); ray.tmax = o.w;
+    HitRec h; TravCounters tc = {0u, 0u, 0u};
+    const bool occluded = traverse<true, false>(sc.nodes, sc.prims, ray, &h, stack + threadIdx.x, TB, &tc);
+    if (!occluded) {
+        float4 L = pa.L[slot];
+        const float4 c = pa.sh_L[slot];
+        L.x += c.x; L.y += c.y; L.z += c.z; L.w += c.w;
+        pa.L[slot] = L;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ shade
+__device__ __forceinline__ Spec4 light_L(const SceneArrays& sc, const DLight& l, const float* lam) {
+    Spec4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = dense_at(sc.pool, l.table, lam[i]) * l.scale;
+    return r;
+}
+
+// block-wide append: returns this lane's index in the output queue (or ~0u when !want)
+__device__ __forceinline__ uint32_t block_append(bool want, uint32_t* __restrict__ counter, uint32_t* lds /* [RB/64 + 1] */) {
+    const unsigned long long mask = __ballot(want);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) lds[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < RB / 64; ++w) { const uint32_t c = lds[w]; lds[w] = tot; tot += c; }
+        lds[RB / 64] = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    const uint32_t idx = lds[RB / 64] + lds[wave] + rank;
+    __syncthreads();
+    return want ? idx : 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(RB) void shade_kernel(RenderConst rc, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ qin,
+                                                   const uint32_t* __restrict__ count_in, uint32_t* __restrict__ qout,
+                                                   uint32_t* __restrict__ count_out, uint32_t* __restrict__ shadow_count) {
+    __shared__ uint32_t lds_a[RB / 64 + 1], lds_b[RB / 64 + 1];
+    const uint32_t i = blockIdx.x * RB + threadIdx.x;
+    const uint32_t n_in = *count_in;
+    if (blockIdx.x * RB >= n_in) return;             // whole block idle (uniform exit, before any barrier)
+    bool cont = false, want_shadow = false;
+    uint32_t slot = 0;
+    const bool live = i < n_in;
+    if (live) slot = qin[i];
+    uint2 misc = live ? pa.misc[slot] : make_uint2(0xFFFFFFFFu, 0u);
+    if (live && misc.x != 0xFFFFFFFFu) {
+        const float4 hv = pa.hit[slot];
+        const uint32_t prim_id = __float_as_uint(hv.x);
+        float4 b4 = pa.beta[slot], L4 = pa.L[slot];
+        const float4 l4 = pa.lambda[slot];
+        float4 p4 = pa.pdf[slot];
+        float beta[4] = {b4.x, b4.y, b4.z, b4.w}, L[4] = {L4.x, L4.y, L4.z, L4.w};
+        const float lam[4] = {l4.x, l4.y, l4.z, l4.w};
+        float pdfw[4] = {p4.x, p4.y, p4.z, p4.w};
+        int depth = (int)(misc.x & 0xFFu);
+        bool specular = ((misc.x >> 8) & 1u) != 0u;
+        const float4 ro4 = pa.ray_o[slot], rd4 = pa.ray_d[slot];
+        const f3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
+        if (prim_id == 0xFFFFFFFFu) {
+            if (!rc.sample_lights || specular) {
+                for (int k = 0; k < rc.n_infinite; ++k) {
+                    const Spec4 le = light_L(sc, sc.lights[sc.infinite[k]], lam);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) L[c] += beta[c] * le.v[c];
+                }
+                pa.L[slot] = make_float4(L[0], L[1], L[2], L[3]);
+            }
+        } else if (depth != rc.max_depth) {
+            depth++;
+            // ---- interaction
+            const uint32_t ref = sc.prim_ref[prim_id];
+            SurfInt si;
+            if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], ro, rd, hv.y);
+            else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w);
+            // ---- BSDF (materials/material.rs:122-195)
+            const DMaterial mat = sc.materials[sc.prim_material[prim_id]];
+            Bsdf bsdf;
+            bsdf.type = mat.type;
+            if (mat.type == PM_MAT_DIFFUSE) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) bsdf.refl.v[c] = clampf(spectrum_at(sc.pool, mat.spec, lam[c]), 0.0f, 1.0f);
+                bsdf.eta = 1.0f; bsdf.tr.ax = 0.0f; bsdf.tr.ay = 0.0f;
+            } else {
+                bsdf.refl = spec_c(0.0f);
+                bsdf.eta = spectrum_at(sc.pool, mat.spec, lam[0]);
+                if (mat.spec.kind != PM_SPEC_CONSTANT) {   // SampledWavelengths::terminate_secondary
+                    if (!(pdfw[1] == 0.0f && pdfw[2] == 0.0f && pdfw[3] == 0.0f)) { pdfw[0] /= 4.0f; pdfw[1] = 0.0f; pdfw[2] = 0.0f; pdfw[3] = 0.0f; }
+                    pa.pdf[slot] = make_float4(pdfw[0], pdfw[1], pdfw[2], pdfw[3]);
+                }
+                float ur = mat.ur, vr = mat.vr;
+                if (mat.remap) { ur = sqrtf(ur); vr = sqrtf(vr); }
+                bsdf.tr.ax = ur; bsdf.tr.ay = vr;
+            }
+            bsdf.fx = norm3(si.dpdus); bsdf.fz = si.ns; bsdf.fy = cross3(bsdf.fz, bsdf.fx);
+            const f3 wo = -rd;
+            const uint4 r4 = pa.rng[slot];
+            Rng rng; rng.state = ((unsigned long long)r4.y << 32) | r4.x; rng.inc = ((unsigned long long)r4.w << 32) | r4.z;
+            // ---- next-event estimation (simple_path.rs:182-213)
+            if (rc.sample_lights) {
+                const float ul = rng_uniform(&rng);
+                if (rc.n_lights > 0) {
+                    const float fi = ul * (float)rc.n_lights;
+                    int idx = fi > 0.0f ? (int)fminf(fi, 2147483520.0f) : 0;
+                    if (idx > rc.n_lights - 1) idx = rc.n_lights - 1;
+                    const float prob = 1.0f / (float)rc.n_lights;
+                    f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
+                    const DLight lt = sc.lights[idx];
+                    Spec4 Ls = light_L(sc, lt, lam);
+                    f3 wi, p_light; float lpdf;
+                    const f3 pm = si_p(si);
+                    if (lt.type == PM_LIGHT_UNIFORM_INFINITE) {
+                        wi = sample_uniform_sphere(u2); lpdf = PM_INV_4PI;
+                        p_light = pm + wi * (2.0f * rc.scene_radius);
+                    } else if (lt.type == PM_LIGHT_DIRECTIONAL) {
+                        wi = norm3(mk3(0.0f * lt.m[0] + 0.0f * lt.m[1] + 1.0f * lt.m[2], 0.0f * lt.m[4] + 0.0f * lt.m[5] + 1.0f * lt.m[6],
+                                       0.0f * lt.m[8] + 0.0f * lt.m[9] + 1.0f * lt.m[10]));
+                        lpdf = 1.0f;
+                        p_light = pm + wi * (2.0f * rc.scene_radius);
+                    } else {
+                        const f3 p = mk3(0.0f * lt.m[0] + 0.0f * lt.m[1] + 0.0f * lt.m[2] + lt.m[3], 0.0f * lt.m[4] + 0.0f * lt.m[5] + 0.0f * lt.m[6] + lt.m[7],
+                                         0.0f * lt.m[8] + 0.0f * lt.m[9] + 0.0f * lt.m[10] + lt.m[11]);
+                        const f3 dv = p - pm;
+                        wi = norm3(dv); lpdf = 1.0f;
+                        const float d2 = dot3(dv, dv);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) Ls.v[c] /= d2;
+                        p_light = p;
+                    }
+                    if (!spec_zero(Ls) && lpdf > 0.0f) {
+                        Spec4 f = bsdf_eval(bsdf, wo, wi);
+                        const float ad = fabsf(dot3(wi, si.ns));
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) f.v[c] *= ad;
+                        if (!spec_zero(f)) {
+                            const f3 dir = p_light - pm;
+                            const f3 so = offset_ray_origin(si, dir);
+                            const float den = prob * lpdf;
+                            pa.sh_o[slot] = make_float4(so.x, so.y, so.z, 1.0f - 0.0001f);
+                            pa.sh_d[slot] = make_float4(dir.x, dir.y, dir.z, 0.f);
+                            pa.sh_L[slot] = make_float4(beta[0] * f.v[0] * Ls.v[0] / den, beta[1] * f.v[1] * Ls.v[1] / den,
+                                                        beta[2] * f.v[2] * Ls.v[2] / den, beta[3] * f.v[3] * Ls.v[3] / den);
+                            want_shadow = true;
+                        }
+                    }
+                }
+            }
+            // ---- continue the path (simple_path.rs:215-265)
+            f3 wi_next = mk3(0.f, 0.f, 0.f);
+            bool ok = false;
+            if (rc.sample_bsdf) {
+                const float uc = rng_uniform(&rng);
+                f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
+                BsdfSample bs;
+                if (bsdf_sample(bsdf, wo, uc, u2, &bs)) {
+                    const float ad = fabsf(dot3(bs.wi, si.ns));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) beta[c] *= bs.value.v[c] * ad / bs.pdf;
+                    specular = (bs.flags & PM_BXDF_SPECULAR) != 0;
+                    wi_next = bs.wi; ok = true;
+                }
+            } else {
+                const int fl = bsdf_flags(bsdf);
+                f3 wi; float spdf;
+                f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
+                if ((fl & PM_BXDF_REFLECTION) && (fl & PM_BXDF_TRANSMISSION)) { wi = sample_uniform_sphere(u2); spdf = PM_INV_4PI; }
+                else {
+                    wi = sample_uniform_hemisphere(u2); spdf = PM_INV_2PI;
+                    const float pr = dot3(wo, si.n) * dot3(wi, si.n);
+                    if (((fl & PM_BXDF_REFLECTION) && pr < 0.0f) || ((fl & PM_BXDF_TRANSMISSION) && pr > 0.0f)) wi = -wi;
+                }
+                const Spec4 f = bsdf_eval(bsdf, wo, wi);
+                const float ad = fabsf(dot3(wi, si.ns));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) beta[c] *= f.v[c] * ad / spdf;
+                specular = false;
+                wi_next = wi; ok = true;
+            }
+            pa.rng[slot] = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), (uint32_t)rng.inc, (uint32_t)(rng.inc >> 32));
+            if (ok && !(beta[0] == 0.0f && beta[1] == 0.0f && beta[2] == 0.0f && beta[3] == 0.0f)) {
+                const f3 no = offset_ray_origin(si, wi_next);
+                pa.ray_o[slot] = make_float4(no.x, no.y, no.z, 0.f);
+                pa.ray_d[slot] = make_float4(wi_next.x, wi_next.y, wi_next.z, 0.f);
+                pa.beta[slot] = make_float4(beta[0], beta[1], beta[2], beta[3]);
+                pa.misc[slot] = make_uint2((uint32_t)depth | (specular ? 1u << 8 : 0u), misc.y);
+                cont = true;
+            }
+        }
+    }
+    const uint32_t oi = block_append(cont, count_out, lds_a);
+    if (cont) qout[oi] = slot;
+    const uint32_t si_ = block_append(want_shadow, shadow_count, lds_b);
+    if (want_shadow) pa.shq[si_] = slot;
+}
+
+// ------------------------------------------------------------------------------------------ accumulate
+__global__ __launch_bounds__(RB) void accumulate_kernel(RenderConst rc, SceneArrays sc, PathArrays pa, double* __restrict__ film) {
+    const uint32_t p = blockIdx.x * RB + threadIdx.x;
+    if (p >= (uint32_t)rc.npix_pad) return;
+    int px, py, s0;
+    if (!slot_pixel(rc, p, &px, &py, &s0)) return;
+    double* fp = film + ((size_t)(py - rc.film_y0) * rc.film_w + (px - rc.film_x0)) * 4;
+    double acc[4] = {fp[0], fp[1], fp[2], fp[3]};
+    for (int s = 0; s < rc.s_count; ++s) {
+        const uint32_t slot = (uint32_t)s * (uint32_t)rc.npix_pad + p;
+        const float4 L4 = pa.L[slot], l4 = pa.lambda[slot], p4 = pa.pdf[slot];
+        const float L[4] = {L4.x, L4.y, L4.z, L4.w}, lam[4] = {l4.x, l4.y, l4.z, l4.w}, pd[4] = {p4.x, p4.y, p4.z, p4.w};
+        const float w = __uint_as_float(pa.misc[slot].y);
+        float Lp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Lp[i] = pd[i] != 0.0f ? (L[i] * 1.0f) / pd[i] : 0.0f;
+        float rgb[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sum += dense_at(sc.pool, rc.sensor_table + 471 * c, lam[i]) * Lp[i];
+            rgb[c] = sum / 4.0f * rc.imaging_ratio;
+        }
+        float m = rgb[0]; if (!(rgb[1] < m)) m = rgb[1]; if (!(rgb[2] < m)) m = rgb[2];
+        if (m > rc.max_component_value) { const float sc_ = rc.max_component_value / m; rgb[0] *= sc_; rgb[1] *= sc_; rgb[2] *= sc_; }
+        const double wd = (double)w;
+        acc[0] += wd * (double)rgb[0]; acc[1] += wd * (double)rgb[1]; acc[2] += wd * (double)rgb[2]; acc[3] += wd;
+    }
+    fp[0] = acc[0]; fp[1] = acc[1]; fp[2] = acc[2]; fp[3] = acc[3];
+}
+
+__global__ void film_add_kernel(double* __restrict__ film, const double* __restrict__ other, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) film[i] += other[i];
+}
+__global__ void film_image_kernel(const double* __restrict__ film, float* __restrict__ rgb, size_t npix, const float* __restrict__ m9) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const double* p = film + i * 4;
+    float c[3] = {(float)p[0], (float)p[1], (float)p[2]};
+    if (p[3] != 0.0) { const float ws = (float)p[3]; c[0] /= ws; c[1] /= ws; c[2] /= ws; }
+    for (int r = 0; r < 3; ++r) {
+        float acc = 0.0f;
+        for (int k = 0; k < 3; ++k) acc += m9[r * 3 + k] * c[k];
+        rgb[i * 3 + r] = acc;
+    }
+}
+
+// ========================================================================================== host side
+struct RenderState {
+    // host copies of what the caller set
+    std::vector<PmMaterial> mats; std::vector<std::vector<float>> mat_tables;
+    std::vector<uint32_t> prim_mat;
+    std::vector<PmLight> lights; std::vector<std::vector<float>> light_tables;
+    PmCamera cam{}; bool have_cam = false;
+    PmFilm film{}; bool have_film = false;
+    std::vector<float> sensor, filter_vals;
+    // device
+    bool scene_dirty = true; const void* accel_tag = nullptr;
+    float* d_pool = nullptr; DMaterial* d_mats = nullptr; DLight* d_lights = nullptr; int* d_inf = nullptr;
+    uint32_t *d_prim_mat = nullptr, *d_prim_ref = nullptr; DShadePatch* d_patches = nullptr; DShadeSphere* d_spheres = nullptr;
+    float* d_m9 = nullptr;
+    int n_inf = 0;
+    DFilter dfilter{}; int sensor_off = 0;
+    double* d_film = nullptr; size_t film_pixels = 0;
+    // path arrays
+    PathArrays pa{}; size_t pa_cap = 0; int pa_depth = 0;
+    std::vector<void*> pa_allocs;
+    PmRenderStats stats{};
+};
+
+void pm_render_state_destroy(pm_ctx* c) {
+    RenderState* r = c->render;
+    if (!r) return;
+    for (void* p : r->pa_allocs) (void)hipFree(p);
+    void* ptrs[] = {r->d_pool, r->d_mats, r->d_lights, r->d_inf, r->d_prim_mat, r->d_prim_ref, r->d_patches, r->d_spheres, r->d_m9, r->d_film};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete r;
+    c->render = nullptr;
+}
+static RenderState* rs(pm_ctx* c) { if (!c->render) c->render = new RenderState(); return c->render; }
+
+static bool spec_needs_table(int kind) { return kind == PM_SPEC_DENSE || kind == PM_SPEC_RGB_ILLUMINANT; }
+
+extern "C" int pm_set_materials(pm_ctx* c, const PmMaterial* m, uint32_t n) {
+    if (!c || (!m && n)) return fail(c, PM_ERR_INVALID, "pm_set_materials: null argument");
+    RenderState* r = rs(c);
+    r->mats.assign(m, m + n); r->mat_tables.assign(n, {});
+    for (uint32_t i = 0; i < n; ++i) {
+        if (m[i].type != PM_MAT_DIFFUSE && m[i].type != PM_MAT_DIELECTRIC) return fail(c, PM_ERR_INVALID, "pm_set_materials: unknown material type");
+        if (m[i].spectrum.kind < PM_SPEC_CONSTANT || m[i].spectrum.kind > PM_SPEC_BLACKBODY) return fail(c, PM_ERR_INVALID, "pm_set_materials: unknown spectrum kind");
+        if (spec_needs_table(m[i].spectrum.kind)) {
+            if (!m[i].spectrum.table) return fail(c, PM_ERR_INVALID, "pm_set_materials: spectrum needs a 471-entry table");
+            r->mat_tables[i].assign(m[i].spectrum.table, m[i].spectrum.table + 471);
+        }
+        r->mats[i].spectrum.table = nullptr;
+    }
+    r->scene_dirty = true;
+    return PM_OK;
+}
+extern "C" int pm_set_prim_materials(pm_ctx* c, const uint32_t* ids, uint32_t n) {
+    if (!c || (!ids && n)) return fail(c, PM_ERR_INVALID, "pm_set_prim_materials: null argument");
+    RenderState* r = rs(c);
+    r->prim_mat.assign(ids, ids + n);
+    r->scene_dirty = true;
+    return PM_OK;
+}
+extern "C" int pm_set_lights(pm_ctx* c, const PmLight* l, uint32_t n) {
+    if (!c || (!l && n)) return fail(c, PM_ERR_INVALID, "pm_set_lights: null argument");
+    RenderState* r = rs(c);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (l[i].type < PM_LIGHT_POINT || l[i].type > PM_LIGHT_UNIFORM_INFINITE) return fail(c, PM_ERR_INVALID, "pm_set_lights: unknown light type");
+        if (!l[i].spectrum) return fail(c, PM_ERR_INVALID, "pm_set_lights: spectrum table missing");
+    }
+    r->lights.assign(l, l + n); r->light_tables.assign(n, {});
+    for (uint32_t i = 0; i < n; ++i) { r->light_tables[i].assign(l[i].spectrum, l[i].spectrum + 471); r->lights[i].spectrum = nullptr; }
+    r->scene_dirty = true;
+    return PM_OK;
+}
+extern "C" int pm_set_camera(pm_ctx* c, const PmCamera* cam) {
+    if (!c || !cam) return fail(c, PM_ERR_INVALID, "pm_set_camera: null argument");
+    const float* m = cam->render_from_camera;
+    if (!(m[12] == 0.f && m[13] == 0.f && m[14] == 0.f && m[15] == 1.f)) return fail(c, PM_ERR_UNSUPPORTED, "pm_set_camera: render_from_camera must be affine");
+    RenderState* r = rs(c);
+    r->cam = *cam; r->have_cam = true;
+    return PM_OK;
+}
+
+// PiecewiseConstant1D::new (sampling/routines.rs:351-387)
+static float pc1d_build(const float* f, int n, float mn, float mx, std::vector<float>& func, std::vector<float>& cdf) {
+    func.resize(n); cdf.resize(n + 1);
+    for (int i = 0; i < n; ++i) func[i] = std::fabs(f[i]);
+    cdf[0] = 0.0f;
+    for (int i = 1; i <= n; ++i) cdf[i] = cdf[i - 1] + func[i - 1] * (mx - mn) / (float)n;
+    const float integral = cdf[n];
+    if (integral == 0.0f) { for (int i = 1; i <= n; ++i) cdf[i] = (float)i / (float)n; }
+    else { for (int i = 0; i <= n; ++i) cdf[i] /= integral; }
+    return integral;
+}
+
+extern "C" int pm_set_film(pm_ctx* c, const PmFilm* f) {
+    if (!c || !f) return fail(c, PM_ERR_INVALID, "pm_set_film: null argument");
+    if (c->device < 0) return fail(c, PM_ERR_INVALID, "pm_set_film: host-only context");
+    const int w = f->pixel_bounds[2] - f->pixel_bounds[0], h = f->pixel_bounds[3] - f->pixel_bounds[1];
+    if (w <= 0 || h <= 0) return fail(c, PM_ERR_INVALID, "pm_set_film: empty pixel_bounds");
+    if (!f->sensor_rgb_bar) return fail(c, PM_ERR_INVALID, "pm_set_film: sensor tables missing");
+    if (f->filter_kind < PM_FILTER_BOX || f->filter_kind > PM_FILTER_GAUSSIAN) return fail(c, PM_ERR_INVALID, "pm_set_film: unknown filter");
+    if (f->filter_kind == PM_FILTER_GAUSSIAN && (!f->filter_vals || f->filter_nx < 1 || f->filter_ny < 1))
+        return fail(c, PM_ERR_INVALID, "pm_set_film: Gaussian filter needs its FilterSampler table");
+    HIPCHK(c, hipSetDevice(c->device));
+    RenderState* r = rs(c);
+    r->film = *f; r->have_film = true;
+    r->sensor.assign(f->sensor_rgb_bar, f->sensor_rgb_bar + 3 * 471);
+    r->filter_vals.clear();
+    if (f->filter_kind == PM_FILTER_GAUSSIAN) r->filter_vals.assign(f->filter_vals, f->filter_vals + (size_t)f->filter_nx * f->filter_ny);
+    r->film.sensor_rgb_bar = nullptr; r->film.filter_vals = nullptr;
+    if (r->d_film) { HIPCHK(c, hipFree(r->d_film)); r->d_film = nullptr; }
+    r->film_pixels = (size_t)w * h;
+    HIPCHK(c, hipMalloc((void**)&r->d_film, r->film_pixels * 4 * sizeof(double)));
+    HIPCHK(c, hipMemset(r->d_film, 0, r->film_pixels * 4 * sizeof(double)));
+    if (!r->d_m9) HIPCHK(c, hipMalloc((void**)&r->d_m9, 9 * sizeof(float)));
+    HIPCHK(c, hipMemcpy(r->d_m9, f->output_rgb_from_sensor_rgb, 9 * sizeof(float), hipMemcpyHostToDevice));
+    r->scene_dirty = true;
+    return PM_OK;
+}
+extern "C" int pm_film_clear(pm_ctx* c) {
+    if (!c || !c->render || !c->render->d_film) return fail(c, PM_ERR_INVALID, "pm_film_clear: no film");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemset(c->render->d_film, 0, c->render->film_pixels * 4 * sizeof(double)));
+    return PM_OK;
+}
+extern "C" int pm_film_read(pm_ctx* c, double* out) {
+    if (!c || !out || !c->render || !c->render->d_film) return fail(c, PM_ERR_INVALID, "pm_film_read: no film");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(out, c->render->d_film, c->render->film_pixels * 4 * sizeof(double),
+                        is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    return PM_OK;
+}
+extern "C" int pm_film_add(pm_ctx* c, const double* in) {
+    if (!c || !in || !c->render || !c->render->d_film) return fail(c, PM_ERR_INVALID, "pm_film_add: no film");
+    HIPCHK(c, hipSetDevice(c->device));
+    RenderState* r = c->render;
+    const size_t n = r->film_pixels * 4;
+    const double* d_in = in; double* tmp = nullptr;
+    if (!is_device_ptr(in)) {
+        HIPCHK(c, hipMalloc((void**)&tmp, n * sizeof(double)));
+        HIPCHK(c, hipMemcpy(tmp, in, n * sizeof(double), hipMemcpyHostToDevice));
+        d_in = tmp;
+    }
+    hipLaunchKernelGGL(film_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, r->d_film, d_in, n);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (tmp) HIPCHK(c, hipFree(tmp));
+    return PM_OK;
+}
+extern "C" int pm_film_image(pm_ctx* c, float* rgb) {
+    if (!c || !rgb || !c->render || !c->render->d_film) return fail(c, PM_ERR_INVALID, "pm_film_image: no film");
+    HIPCHK(c, hipSetDevice(c->device));
+    RenderState* r = c->render;
+    const size_t n = r->film_pixels;
+    float* d_rgb = rgb;
+    const bool dev = is_device_ptr(rgb);
+    if (!dev) HIPCHK(c, hipMalloc((void**)&d_rgb, n * 3 * sizeof(float)));
+    hipLaunchKernelGGL(film_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, r->d_film, d_rgb, n, r->d_m9);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!dev) { HIPCHK(c, hipMemcpy(rgb, d_rgb, n * 3 * sizeof(float), hipMemcpyDeviceToHost)); HIPCHK(c, hipFree(d_rgb)); }
+    return PM_OK;
+}
+
+template <class T>
+static int upload(pm_ctx* c, T** dst, const std::vector<T>& v) {
+    if (*dst) { HIPCHK(c, hipFree(*dst)); *dst = nullptr; }
+    HIPCHK(c, hipMalloc((void**)dst, std::max<size_t>(v.size(), 1) * sizeof(T)));
+    if (!v.empty()) HIPCHK(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return PM_OK;
+}
+
+static int upload_scene(pm_ctx* c, RenderState* r) {
+    const uint32_t n_prims = c->scene.next_prim_id;
+    if (r->prim_mat.size() != n_prims) return fail(c, PM_ERR_INVALID, "pm_render: pm_set_prim_materials must give one material id per primitive");
+    for (uint32_t id : r->prim_mat) if (id >= r->mats.size()) return fail(c, PM_ERR_INVALID, "pm_render: material id out of range");
+    std::vector<float> pool;
+    auto add_table = [&](const std::vector<float>& t) { int off = (int)pool.size(); pool.insert(pool.end(), t.begin(), t.end()); return off; };
+    std::vector<DMaterial> dm(r->mats.size());
+    for (size_t i = 0; i < dm.size(); ++i) {
+        const PmMaterial& m = r->mats[i];
+        dm[i].type = m.type; dm[i].ur = m.u_roughness; dm[i].vr = m.v_roughness; dm[i].remap = m.remap_roughness;
+        dm[i].spec.kind = m.spectrum.kind; dm[i].spec.a = m.spectrum.a; dm[i].spec.b = m.spectrum.b; dm[i].spec.c = m.spectrum.c; dm[i].spec.d = m.spectrum.d;
+        dm[i].spec.table = r->mat_tables[i].empty() ? -1 : add_table(r->mat_tables[i]);
+    }
+    std::vector<DLight> dl(r->lights.size());
+    std::vector<int> inf;
+    for (size_t i = 0; i < dl.size(); ++i) {
+        dl[i].type = r->lights[i].type; dl[i].scale = r->lights[i].scale;
+        std::memcpy(dl[i].m, r->lights[i].render_from_light, 48);
+        dl[i].table = add_table(r->light_tables[i]);
+        if (dl[i].type == PM_LIGHT_UNIFORM_INFINITE) inf.push_back((int)i);   // integrators/base.rs:57-63
+    }
+    r->n_inf = (int)inf.size();
+    r->sensor_off = add_table(r->sensor);
+    // FilterSampler distribution (imaging/filter.rs:187-216, sampling/routines.rs:437-462)
+    DFilter df{};
+    df.kind = r->film.filter_kind; df.rx = r->film.filter_radius[0]; df.ry = r->film.filter_radius[1];
+    if (df.kind == PM_FILTER_GAUSSIAN) {
+        df.nx = r->film.filter_nx; df.ny = r->film.filter_ny;
+        std::vector<float> vals_abs, cond_cdf, cond_int(df.ny), func, cdf;
+        for (int v = 0; v < df.ny; ++v) {
+            cond_int[v] = pc1d_build(&r->filter_vals[(size_t)v * df.nx], df.nx, -df.rx, df.rx, func, cdf);
+            cond_cdf.insert(cond_cdf.end(), cdf.begin(), cdf.end());
+        }
+        std::vector<float> mfunc, mcdf;
+        df.marg_int = pc1d_build(cond_int.data(), df.ny, -df.ry, df.ry, mfunc, mcdf);
+        for (float x : r->filter_vals) if (x < 0.0f) return fail(c, PM_ERR_UNSUPPORTED, "pm_set_film: negative filter table entries");
+        df.vals = add_table(r->filter_vals); df.cond_cdf = add_table(cond_cdf); df.cond_int = add_table(cond_int);
+        df.marg_func = add_table(mfunc); df.marg_cdf = add_table(mcdf);
+    }
+    r->dfilter = df;
+    // shading records, by primitive id
+    std::vector<uint32_t> ref(n_prims);
+    std::vector<DShadePatch> sp; std::vector<DShadeSphere> ss;
+    sp.reserve(c->scene.patches.size() + c->scene.tris.size());
+    for (const auto& p : c->scene.patches) {
+        DShadePatch d{}; std::memcpy(d.p, p.p, 48); d.flags = p.flip_normal ? 1u : 0u;
+        ref[p.prim_id] = ((uint32_t)PM_PRIM_PATCH << 30) | (uint32_t)sp.size(); sp.push_back(d);
+    }
+    for (const auto& t : c->scene.tris) {
+        DShadePatch d{}; std::memcpy(d.p, t.v, 36); std::memcpy(d.p + 9, t.v[2], 12); d.flags = 0u;
+        ref[t.prim_id] = ((uint32_t)PM_PRIM_PATCH << 30) | (uint32_t)sp.size(); sp.push_back(d);
+    }
+    for (const auto& s : c->scene.spheres) {
+        DShadeSphere d{};
+        std::memcpy(d.rfo, s.render_from_object, 48); std::memcpy(d.ofr, s.object_from_render, 48);
+        d.radius = s.radius; d.z_min = s.z_min; d.z_max = s.z_max; d.phi_max = s.phi_max; d.th_min = s.theta_z_min; d.th_max = s.theta_z_max;
+        d.flags = s.reverse_orientation ? 1u : 0u;
+        ref[s.prim_id] = ((uint32_t)PM_PRIM_SPHERE << 30) | (uint32_t)ss.size(); ss.push_back(d);
+    }
+    int rc;
+    if ((rc = upload(c, &r->d_pool, pool))) return rc;
+    if ((rc = upload(c, &r->d_mats, dm))) return rc;
+    if ((rc = upload(c, &r->d_lights, dl))) return rc;
+    if ((rc = upload(c, &r->d_inf, inf))) return rc;
+    if ((rc = upload(c, &r->d_prim_mat, r->prim_mat))) return rc;
+    if ((rc = upload(c, &r->d_prim_ref, ref))) return rc;
+    if ((rc = upload(c, &r->d_patches, sp))) return rc;
+    if ((rc = upload(c, &r->d_spheres, ss))) return rc;
+    r->scene_dirty = false;
+    r->accel_tag = c->d_nodes;
+    return PM_OK;
+}
+
+static int ensure_paths(pm_ctx* c, RenderState* r, size_t npaths, int max_depth) {
+    if (r->pa_cap >= npaths && r->pa_depth >= max_depth) return PM_OK;
+    for (void* p : r->pa_allocs) HIPCHK(c, hipFree(p));
+    r->pa_allocs.clear(); r->pa_cap = 0;
+    auto al = [&](void** p, size_t bytes) -> int { HIPCHK(c, hipMalloc(p, bytes)); r->pa_allocs.push_back(*p); return PM_OK; };
+    PathArrays& pa = r->pa;
+    float4** f4[] = {&pa.ray_o, &pa.ray_d, &pa.beta, &pa.L, &pa.lambda, &pa.pdf, &pa.hit, &pa.sh_o, &pa.sh_d, &pa.sh_L};
+    int rc;
+    for (auto p : f4) if ((rc = al((void**)p, npaths * sizeof(float4)))) return rc;
+    if ((rc = al((void**)&pa.rng, npaths * sizeof(uint4)))) return rc;
+    if ((rc = al((void**)&pa.misc, npaths * sizeof(uint2)))) return rc;
+    if ((rc = al((void**)&pa.q0, npaths * 4))) return rc;
+    if ((rc = al((void**)&pa.q1, npaths * 4))) return rc;
+    if ((rc = al((void**)&pa.shq, npaths * 4))) return rc;
+    if ((rc = al((void**)&pa.counts, 2 * (size_t)(max_depth + 2) * 4))) return rc;
+    r->pa_cap = npaths; r->pa_depth = max_depth;
+    return PM_OK;
+}
+
+static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int dpx, int dpy, int ds, float* out13) {
+    if (!c || !p) return fail(c, PM_ERR_INVALID, "pm_render: null argument");
+    if (c->device < 0) return fail(c, PM_ERR_INVALID, "pm_render: host-only context");
+    if (!c->accel_valid) return fail(c, PM_ERR_NO_ACCEL, "pm_render: pm_build_accel has not been called");
+    RenderState* r = rs(c);
+    if (!r->have_cam || !r->have_film) return fail(c, PM_ERR_INVALID, "pm_render: camera and film must be set");
+    if (p->integrator == PM_INTEGRATOR_RANDOM_WALK) return fail(c, PM_ERR_UNSUPPORTED, "pm_render: RandomWalkIntegrator is not on the GPU path yet");
+    if (p->integrator != PM_INTEGRATOR_SIMPLE_PATH) return fail(c, PM_ERR_INVALID, "pm_render: unknown integrator");
+    if (p->max_depth < 0 || p->max_depth > 254) return fail(c, PM_ERR_INVALID, "pm_render: max_depth out of range");
+    const int* pb = r->film.pixel_bounds;
+    int x0 = p->window[0], y0 = p->window[1], x1 = p->window[2], y1 = p->window[3], s0 = p->s0, s1 = p->s1;
+    if (debug_one) { x0 = dpx; y0 = dpy; x1 = dpx + 1; y1 = dpy + 1; s0 = ds; s1 = ds + 1; }
+    if (x0 < pb[0] || y0 < pb[1] || x1 > pb[2] || y1 > pb[3] || x0 > x1 || y0 > y1) return fail(c, PM_ERR_INVALID, "pm_render: window outside pixel_bounds");
+    // IndependentSampler::start_pixel_sample errors for sample_index >= samples_per_pixel (sampler.rs:110-122)
+    if (s0 < 0 || s1 > p->spp || s0 > s1) return fail(c, PM_ERR_INVALID, "pm_render: sample window outside [0, spp)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rcode;
+    if (r->scene_dirty || r->accel_tag != c->d_nodes) if ((rcode = upload_scene(c, r))) return rcode;
+    r->stats = PmRenderStats{};
+    r->stats.state_bytes_per_path = 10 * 16 + 16 + 8 + 12;
+    const int W = x1 - x0, H = y1 - y0;
+    if (W == 0 || H == 0 || s0 == s1) return PM_OK;
+    const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
+    const size_t npix_pad = (size_t)tiles_x * tiles_y * 64;
+    const size_t target = (size_t)1 << 23;
+    int s_per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)(s1 - s0), target / npix_pad));
+    const size_t max_paths = npix_pad * (size_t)s_per_pass;
+    if (max_paths > 0x7FFFFFFFull) return fail(c, PM_ERR_INVALID, "pm_render: window too large for one pass");
+    if ((rcode = ensure_paths(c, r, max_paths, p->max_depth))) return rcode;
+
+    RenderConst rc{};
+    std::memcpy(rc.cfr, r->cam.camera_from_raster, 64); std::memcpy(rc.rfc, r->cam.render_from_camera, 48);
+    rc.lens_radius = r->cam.lens_radius; rc.focal_distance = r->cam.focal_distance;
+    rc.filter = r->dfilter; rc.sensor_table = r->sensor_off;
+    rc.imaging_ratio = r->film.imaging_ratio; rc.max_component_value = r->film.max_component_value;
+    rc.integrator = p->integrator; rc.max_depth = p->max_depth; rc.sample_lights = p->sample_lights; rc.sample_bsdf = p->sample_bsdf;
+    rc.seed = p->seed; rc.n_lights = (int)r->lights.size(); rc.n_infinite = r->n_inf;
+    {   // SceneData::new -> light.preprocess(scene_bounds): Bounds3f::bounding_sphere (core/bounds.rs:588-597)
+        const pm::Box& b = c->accel.bounds;
+        float ctr[3], d2 = 0.0f; bool inside = true;
+        for (int k = 0; k < 3; ++k) { ctr[k] = (b.lo[k] + b.hi[k]) / 2.0f; inside = inside && ctr[k] >= b.lo[k] && ctr[k] <= b.hi[k]; }
+        const float dx = ctr[0] - b.hi[0], dy = ctr[1] - b.hi[1], dz = ctr[2] - b.hi[2];
+        d2 = dx * dx + dy * dy + dz * dz;
+        rc.scene_radius = inside ? std::sqrt(d2) : 0.0f;
+    }
+    rc.win_x0 = x0; rc.win_y0 = y0; rc.win_w = W; rc.win_h = H; rc.tiles_x = tiles_x; rc.npix_pad = (int)npix_pad;
+    rc.film_x0 = pb[0]; rc.film_y0 = pb[1]; rc.film_w = pb[2] - pb[0];
+    SceneArrays sa{c->d_nodes, c->d_prims, r->d_prim_ref, r->d_patches, r->d_spheres, r->d_prim_mat, r->d_mats, r->d_lights, r->d_inf, r->d_pool};
+    PathArrays& pa = r->pa;
+    const int nb = p->max_depth + 2;
+    std::vector<uint32_t> hcounts(2 * (size_t)nb);
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    for (int sb = s0; sb < s1; sb += s_per_pass) {
+        rc.s_base = sb; rc.s_count = std::min(s_per_pass, s1 - sb);
+        const uint32_t npaths = (uint32_t)(npix_pad * (size_t)rc.s_count);
+        HIPCHK(c, hipMemsetAsync(pa.counts, 0, 2 * (size_t)nb * 4, c->stream));
+        const dim3 gr((npaths + RB - 1) / RB), gt((npaths + TB - 1) / TB);
+        hipLaunchKernelGGL(raygen_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, npaths);
+        uint32_t *qin = pa.q0, *qout = pa.q1;
+        for (int b = 0; b <= p->max_depth; ++b) {
+            uint32_t* cnt_in = pa.counts + b; uint32_t* cnt_out = pa.counts + b + 1; uint32_t* cnt_sh = pa.counts + nb + b;
+            hipLaunchKernelGGL(closest_kernel, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in);
+            hipLaunchKernelGGL(shade_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, qin, cnt_in, qout, cnt_out, cnt_sh);
+            if (p->sample_lights && b < p->max_depth)
+                hipLaunchKernelGGL(shadow_kernel, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh);
+            std::swap(qin, qout);
+            r->stats.kernels_launched += 3;
+        }
+        if (!debug_one)
+            hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((npix_pad + RB - 1) / RB)), dim3(RB), 0, c->stream, rc, sa, pa, r->d_film);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(hcounts.data(), pa.counts, hcounts.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        r->stats.passes++;
+        r->stats.samples += (uint64_t)W * H * rc.s_count;
+        // closest rays: every live path in the queue of bounce b (padded slots are not live)
+        const uint64_t pad = (uint64_t)(npix_pad - (size_t)W * H) * rc.s_count;
+        for (int b = 0; b <= p->max_depth; ++b) r->stats.closest_rays += hcounts[b] - (b == 0 ? pad : 0);
+        for (int b = 0; b < nb; ++b) r->stats.shadow_rays += hcounts[nb + b];
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    r->stats.kernel_ms = ms; c->last_ms = ms;
+    if (debug_one) {
+        float4 h[3]; uint2 m;
+        HIPCHK(c, hipMemcpy(&h[0], pa.L, 16, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&h[1], pa.lambda, 16, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&h[2], pa.pdf, 16, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&m, pa.misc, 8, hipMemcpyDeviceToHost));
+        std::memcpy(out13, h, 48);
+        std::memcpy(out13 + 12, &m.y, 4);
+    }
+    return PM_OK;
+}
+
+extern "C" int pm_render(pm_ctx* c, const PmRenderParams* p) { return render_impl(c, p, false, 0, 0, 0, nullptr); }
+extern "C" int pm_debug_sample(pm_ctx* c, const PmRenderParams* p, int32_t px, int32_t py, int32_t s, float* out13) {
+    if (!out13) return fail(c, PM_ERR_INVALID, "pm_debug_sample: null out");
+    return render_impl(c, p, true, px, py, s, out13);
+}
+extern "C" int pm_get_render_stats(pm_ctx* c, PmRenderStats* out) {
+    if (!c || !out || !c->render) return fail(c, PM_ERR_INVALID, "pm_get_render_stats: nothing rendered");
+    *out = c->render->stats;
+    return PM_OK;
+}

@@ -1,0 +1,255 @@
+"""Host-side scene construction over the `pmh_*` helpers (include/pbrt_mi355_host.h).
+
+Mirrors the constructor calls of the reference's `render_cpu()` (src/main.rs:43-234): Transform::look_at,
+PerspectiveCamera::builder, GaussianFilter::new, PixelSensor::with_xyz_matching, RGBFilm::new,
+RgbIlluminantSpectrum / BlackbodySpectrum / RgbAlbedoSpectrum, UniformInfiniteLight / DirectionalLight /
+PointLight, DiffuseMaterial / DielectricMaterial — and flattens the result into the C-ABI structs.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from ._capi import (PM_FILTER_BOX, PM_FILTER_GAUSSIAN, PM_LIGHT_DIRECTIONAL, PM_LIGHT_POINT,
+                    PM_LIGHT_UNIFORM_INFINITE, PM_MAT_DIELECTRIC, PM_MAT_DIFFUSE, PM_SPEC_CONSTANT, PM_SPEC_DENSE,
+                    PM_SPEC_RGB_ALBEDO, PmCamera, PmFilm, PmLight, PmMaterial, PmSpectrum)
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "cie_tables.npz")
+
+
+def _p(a):
+    return a.ctypes.data
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Transform:
+    """core/transform.rs Transform {m, m_inv}, row-major float32 4x4."""
+
+    def __init__(self, m, m_inv):
+        self.m = _f32(m).reshape(4, 4)
+        self.m_inv = _f32(m_inv).reshape(4, 4)
+
+    IDENTITY = None
+
+    @staticmethod
+    def translate(delta):
+        m = np.eye(4, dtype=np.float32)
+        mi = np.eye(4, dtype=np.float32)
+        m[:3, 3] = _f32(delta)
+        mi[:3, 3] = -_f32(delta)
+        return Transform(m, mi)
+
+    @staticmethod
+    def from_matrix(m):
+        m = _f32(m).reshape(4, 4)
+        out = np.zeros((4, 4), np.float32)
+        if _capi.lib().pmh_mat4_inverse(_p(m), _p(out)) != 0:
+            raise ValueError("singular matrix")
+        return Transform(m, out)
+
+    @staticmethod
+    def look_at(pos, look, up):
+        m = np.zeros((4, 4), np.float32)
+        mi = np.zeros((4, 4), np.float32)
+        a, b, c = _f32(pos), _f32(look), _f32(up)
+        if _capi.lib().pmh_look_at(_p(a), _p(b), _p(c), _p(m), _p(mi)) != 0:
+            raise ValueError("degenerate look_at")
+        return Transform(m, mi)
+
+    def inverse(self):
+        return Transform(self.m_inv, self.m)
+
+    def __mul__(self, other):
+        m = np.zeros((4, 4), np.float32)
+        mi = np.zeros((4, 4), np.float32)
+        L = _capi.lib()
+        L.pmh_mat4_mul(_p(self.m), _p(other.m), _p(m))
+        L.pmh_mat4_mul(_p(other.m_inv), _p(self.m_inv), _p(mi))
+        return Transform(m, mi)
+
+
+Transform.IDENTITY = Transform(np.eye(4), np.eye(4))
+
+
+class Spectra:
+    """CIE tables, the sRGB colour space illuminant and the spectrum constructors of sampling/spectrum.rs."""
+
+    def __init__(self):
+        d = np.load(_DATA)
+        self.cie_x, self.cie_y, self.cie_z = (_f32(d[k]) for k in ("cie_x", "cie_y", "cie_z"))
+        d65i = _f32(d["d65_interleaved"])
+        self.d65 = np.zeros(471, np.float32)
+        L = _capi.lib()
+        L.pmh_d65_table(_p(self.cie_y), _p(d65i), len(d65i), _p(self.d65))
+        self.xyz_from_rgb = np.zeros(9, np.float32)
+        self.rgb_from_xyz = np.zeros(9, np.float32)
+        if L.pmh_srgb_matrices(_p(self.cie_x), _p(self.cie_y), _p(self.cie_z), _p(self.d65), _p(self.xyz_from_rgb),
+                               _p(self.rgb_from_xyz)) != 0:
+            raise RuntimeError("sRGB matrices")
+
+    def photometric(self, table):
+        return float(_capi.lib().pmh_photometric(_p(self.cie_y), _p(_f32(table))))
+
+    def rgb_coeffs(self, rgb):
+        """RGBColorSpace::to_rgb_coeffs for sRGB (solved, not looked up: the table file is missing upstream)."""
+        out = np.zeros(3, np.float32)
+        rgb = _f32(np.maximum(rgb, 0))
+        rc = _capi.lib().pmh_rgb_to_coeffs(_p(rgb), _p(self.cie_x), _p(self.cie_y), _p(self.cie_z), _p(self.d65),
+                                           _p(self.xyz_from_rgb), _p(out))
+        if rc != 0:
+            raise RuntimeError("rgb_to_coeffs failed")
+        return out
+
+    def rgb_albedo(self, rgb):
+        """RgbAlbedoSpectrum::new(&SRGB, rgb) -> ('rgb_albedo', c0, c1, c2)"""
+        c = self.rgb_coeffs(rgb)
+        return {"kind": PM_SPEC_RGB_ALBEDO, "a": float(c[0]), "b": float(c[1]), "c": float(c[2])}
+
+    def rgb_illuminant_table(self, rgb):
+        """RgbIlluminantSpectrum::new(&SRGB, rgb) densified as lights do (lights/base.rs:177-188)."""
+        rgb = _f32(rgb)
+        m = float(max(rgb))
+        scale = np.float32(2.0) * np.float32(m)
+        c = self.rgb_coeffs(rgb / scale if scale != 0 else np.zeros(3, np.float32))
+        out = np.zeros(471, np.float32)
+        _capi.lib().pmh_rgb_spectrum_table(_p(c), C.c_float(scale), _p(self.d65), _p(out))
+        return out, c, float(scale)
+
+    def blackbody_table(self, temp):
+        out = np.zeros(471, np.float32)
+        _capi.lib().pmh_blackbody_table(C.c_float(temp), _p(out))
+        return out
+
+    def constant_table(self, c):
+        return np.full(471, c, np.float32)
+
+    def sensor_xyz_tables(self):
+        """PixelSensor::with_xyz_matching: r_bar, g_bar, b_bar = X, Y, Z (camera/sensor.rs:85-111)"""
+        return np.ascontiguousarray(np.concatenate([self.cie_x, self.cie_y, self.cie_z]).astype(np.float32))
+
+
+def constant_spectrum(c):
+    return {"kind": PM_SPEC_CONSTANT, "a": float(c)}
+
+
+def dense_spectrum(table):
+    return {"kind": PM_SPEC_DENSE, "table": _f32(table)}
+
+
+def diffuse(reflectance):
+    """DiffuseMaterial::new(ConstantSpectrumTexture(reflectance))"""
+    return {"type": PM_MAT_DIFFUSE, "spectrum": reflectance, "u_roughness": 0.0, "v_roughness": 0.0, "remap": False}
+
+
+def dielectric(eta, u_roughness=0.0, v_roughness=0.0, remap_roughness=False):
+    """DielectricMaterial::new(u_rough, v_rough, remap, eta)"""
+    return {"type": PM_MAT_DIELECTRIC, "spectrum": eta, "u_roughness": float(u_roughness),
+            "v_roughness": float(v_roughness), "remap": bool(remap_roughness)}
+
+
+def light(kind, table, scale, render_from_light=None):
+    m = np.eye(4, dtype=np.float32) if render_from_light is None else _f32(render_from_light).reshape(4, 4)
+    return {"type": kind, "scale": float(np.float32(scale)), "m": m, "table": _f32(table)}
+
+
+class SceneDescription:
+    """Everything `SimplePathIntegrator::new(...)` + `render()` consume, flattened."""
+
+    def __init__(self):
+        self.prims = []            # Sphere | BilinearPatchMesh | TriangleMesh, insertion order
+        self.prim_materials = []   # one material id per primitive (meshes contribute one id per face)
+        self.materials = []
+        self.lights = []
+        self.camera = None         # PmCamera
+        self.film = None           # dict, see make_film
+        self.render_from_world = None
+        self._keep = []
+
+    # -- flattening into ctypes (kept alive by self._keep) ------------------------------------------
+    def c_materials(self):
+        arr = (PmMaterial * max(1, len(self.materials)))()
+        for i, m in enumerate(self.materials):
+            arr[i].type = m["type"]
+            sp = m["spectrum"]
+            arr[i].spectrum.kind = sp["kind"]
+            for k in "abcd":
+                setattr(arr[i].spectrum, k, float(sp.get(k, 0.0)))
+            if "table" in sp:
+                t = _f32(sp["table"])
+                self._keep.append(t)
+                arr[i].spectrum.table = t.ctypes.data_as(C.POINTER(C.c_float))
+            arr[i].u_roughness, arr[i].v_roughness = m["u_roughness"], m["v_roughness"]
+            arr[i].remap_roughness = int(m["remap"])
+        return arr
+
+    def c_lights(self):
+        arr = (PmLight * max(1, len(self.lights)))()
+        for i, l in enumerate(self.lights):
+            arr[i].type = l["type"]
+            arr[i].scale = l["scale"]
+            arr[i].render_from_light[:] = l["m"].reshape(-1).tolist()
+            self._keep.append(l["table"])
+            arr[i].spectrum = l["table"].ctypes.data_as(C.POINTER(C.c_float))
+        return arr
+
+    def c_prim_materials(self):
+        return np.ascontiguousarray(self.prim_materials, dtype=np.uint32)
+
+    def c_film(self):
+        f = self.film
+        out = PmFilm()
+        out.full_resolution[:] = list(f["full_resolution"])
+        out.pixel_bounds[:] = list(f["pixel_bounds"])
+        out.max_component_value = f["max_component_value"]
+        out.imaging_ratio = f["imaging_ratio"]
+        out.output_rgb_from_sensor_rgb[:] = _f32(f["output_rgb_from_sensor_rgb"]).reshape(-1).tolist()
+        self._keep.append(f["sensor"])
+        out.sensor_rgb_bar = f["sensor"].ctypes.data_as(C.POINTER(C.c_float))
+        out.filter_kind = f["filter_kind"]
+        out.filter_radius[:] = list(f["filter_radius"])
+        if f["filter_kind"] == PM_FILTER_GAUSSIAN:
+            out.filter_nx, out.filter_ny = f["filter_nx"], f["filter_ny"]
+            self._keep.append(f["filter_vals"])
+            out.filter_vals = f["filter_vals"].ctypes.data_as(C.POINTER(C.c_float))
+        return out
+
+
+def make_camera(world_from_camera, fov, resolution, screen_window=(-1.0, -1.0, 1.0, 1.0), lens_radius=0.0,
+                focal_distance=10e30):
+    """PerspectiveCamera::builder()...build() (camera/perspective.rs:30-86). Returns (PmCamera, render_from_world)."""
+    cam = PmCamera()
+    wfr = np.zeros((4, 4), np.float32)
+    rfw = np.zeros((4, 4), np.float32)
+    sw = _f32(screen_window)
+    rc = _capi.lib().pmh_perspective_camera(_p(world_from_camera.m), _p(world_from_camera.m_inv), C.c_float(fov), _p(sw),
+                                            int(resolution[0]), int(resolution[1]), C.c_float(lens_radius),
+                                            C.c_float(min(focal_distance, 3.0e38)), C.byref(cam), _p(wfr), _p(rfw))
+    if rc != 0:
+        raise RuntimeError("perspective camera")
+    return cam, Transform(rfw, wfr)
+
+
+def make_film(spectra, resolution, pixel_bounds=None, filter_kind=PM_FILTER_GAUSSIAN, filter_radius=(1.5, 1.5), sigma=0.5,
+              imaging_ratio=1.0, max_component_value=float("inf")):
+    """RGBFilm::new(RGBFilmParams{.., sensor: PixelSensor::with_xyz_matching(&SRGB, None, ratio), color_space: &SRGB})"""
+    w, h = resolution
+    film = {"full_resolution": (w, h), "pixel_bounds": tuple(pixel_bounds) if pixel_bounds else (0, 0, w, h),
+            "max_component_value": float(max_component_value), "imaging_ratio": float(imaging_ratio),
+            # output_rgb_from_sensor_rgb = rgb_from_xyz * xyz_from_sensor_rgb (identity for the XYZ sensor) (film.rs:128-129)
+            "output_rgb_from_sensor_rgb": spectra.rgb_from_xyz.copy(), "sensor": spectra.sensor_xyz_tables(),
+            "filter_kind": filter_kind, "filter_radius": (float(filter_radius[0]), float(filter_radius[1]))}
+    if filter_kind == PM_FILTER_GAUSSIAN:
+        nx, ny = C.c_int(), C.c_int()
+        L = _capi.lib()
+        L.pmh_gaussian_filter_table(C.c_float(filter_radius[0]), C.c_float(filter_radius[1]), C.c_float(sigma), None, 0,
+                                    C.byref(nx), C.byref(ny))
+        vals = np.zeros(nx.value * ny.value, np.float32)
+        if L.pmh_gaussian_filter_table(C.c_float(filter_radius[0]), C.c_float(filter_radius[1]), C.c_float(sigma), _p(vals),
+                                       vals.size, C.byref(nx), C.byref(ny)) != 0:
+            raise RuntimeError("filter table")
+        film.update(filter_nx=nx.value, filter_ny=ny.value, filter_vals=vals)
+    return film

@@ -88,3 +88,122 @@ def incoherent_rays(n, seed=2, radius=1.9):
     rays["d"] = d
     rays["tmax"] = np.inf
     return rays
+
+
+# ------------------------------------------------------------------------------------------------
+# full scenes for the path tracer (C1: src/main.rs:43-234 verbatim; C2: Cornell box as triangles)
+# ------------------------------------------------------------------------------------------------
+def _xf_points(m, pts):
+    """Transform * Point3f for an affine matrix, f32, in the reference's operation order (transform.rs:320-335)."""
+    m = np.asarray(m, np.float32)
+    p = np.asarray(pts, np.float32)
+    x = p[:, 0] * m[0, 0] + p[:, 1] * m[0, 1] + p[:, 2] * m[0, 2] + m[0, 3]
+    y = p[:, 0] * m[1, 0] + p[:, 1] * m[1, 1] + p[:, 2] * m[1, 2] + m[1, 3]
+    z = p[:, 0] * m[2, 0] + p[:, 1] * m[2, 1] + p[:, 2] * m[2, 2] + m[2, 3]
+    return np.stack([x, y, z], axis=1).astype(np.float32)
+
+
+def main_rs_scene(resolution=(400, 400), spectra=None):
+    """The hardcoded scene of the reference binary (src/main.rs:43-234): 3 spheres + floor quad, sky + sun."""
+    from . import host
+    from .aggregate import BilinearPatchMesh, Sphere
+    f32 = np.float32
+    sp = spectra or host.Spectra()
+    sd = host.SceneDescription()
+    camera_from_world = host.Transform.look_at((3.0, 4.0, 1.5), (0.5, 0.5, 0.0), (0.0, 0.0, 1.0))
+    sd.film = host.make_film(sp, resolution, filter_kind=host.PM_FILTER_GAUSSIAN, filter_radius=(1.5, 1.5), sigma=0.5)
+    sd.camera, rfw = host.make_camera(camera_from_world.inverse(), 45.0, resolution, lens_radius=0.0, focal_distance=10e30)
+    sd.render_from_world = rfw
+    # lights (main.rs:89-112)
+    sky_table, _, _ = sp.rgb_illuminant_table((0.4, 0.45, 0.5))
+    sky_scale = f32(1.0) / f32(sp.photometric(sp.d65))          # RgbIlluminantSpectrum::to_photometric = illuminant's
+    sd.lights.append(host.light(host.PM_LIGHT_UNIFORM_INFINITE, sky_table, sky_scale))
+    w = np.array([-30.0, 40.0, 100.0], f32) - np.array([0.0, 0.0, 1.0], f32)
+    w = w / np.sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2], dtype=f32)
+    if abs(w[0]) > abs(w[1]):
+        v2 = np.array([-w[2], 0.0, w[0]], f32) / np.sqrt(w[0] * w[0] + w[2] * w[2], dtype=f32)
+    else:
+        v2 = np.array([0.0, w[2], -w[1]], f32) / np.sqrt(w[1] * w[1] + w[2] * w[2], dtype=f32)
+    v3 = np.cross(w.astype(np.float64), v2.astype(np.float64)).astype(f32)
+    # (w, v1, v2) = w.coordinate_system()  ->  v1 := v2 above, v2 := v3
+    sun_m = np.array([[v2[0], v3[0], w[0], 0], [v2[1], v3[1], w[1], 0], [v2[2], v3[2], w[2], 0], [0, 0, 0, 1]], f32)
+    sun_xf = rfw * host.Transform.from_matrix(sun_m)
+    sun_table = sp.blackbody_table(3000.0)
+    sun_scale = f32(1.5) / f32(sp.photometric(sun_table))
+    sd.lights.append(host.light(host.PM_LIGHT_DIRECTIONAL, sun_table, sun_scale, sun_xf.m))
+    # materials
+    sd.materials = [host.dielectric(host.constant_spectrum(1.5), 0.0, 0.0, False),
+                    host.diffuse(sp.rgb_albedo((0.8, 0.8, 0.8))),
+                    host.diffuse(sp.rgb_albedo((0.8, 0.45, 0.15))),
+                    host.diffuse(sp.rgb_albedo((0.8, 0.25, 0.3)))]
+
+    def sphere(radius, centre):
+        t = rfw * host.Transform.translate(centre)
+        return Sphere(radius, -radius, radius, 360.0, t.m, t.m_inv, False)
+
+    floor_xf = rfw * host.Transform.translate((0.0, 0.0, -1.0))
+    floor_pos = _xf_points(floor_xf.m, [[-20, -20, 0], [20, -20, 0], [-20, 20, 0], [20, 20, 0]])
+    sd.prims = [sphere(1.0, (0.0, 0.0, 0.0)), BilinearPatchMesh(floor_pos, [[0, 1, 2, 3]]),
+                sphere(1.5, (-3.5, -2.0, 0.5)), sphere(0.75, (-0.3, -3.0, -0.25))]
+    sd.prim_materials = [0, 1, 2, 3]          # main.rs:217-219 order: sphere, floor, sphere2, sphere3
+    return sd
+
+
+def cornell_scene(resolution=(1024, 1024), spectra=None, glass_sphere=True):
+    """C2: a Cornell box built from triangles (walls, tall box, short box), lit by a PointLight just under the
+    ceiling (the reference has no area light, lights/base.rs:18-22), seen through a PerspectiveCamera.
+    Optionally one smooth dielectric sphere (divergent specular paths)."""
+    from . import host
+    from .aggregate import Sphere, TriangleMesh
+    f32 = np.float32
+    sp = spectra or host.Spectra()
+    sd = host.SceneDescription()
+    camera_from_world = host.Transform.look_at((0.0, 0.0, 3.9), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+    sd.film = host.make_film(sp, resolution, filter_kind=host.PM_FILTER_GAUSSIAN, filter_radius=(1.5, 1.5), sigma=0.5)
+    sd.camera, rfw = host.make_camera(camera_from_world.inverse(), 38.0, resolution)
+    sd.render_from_world = rfw
+    white, red, green, glass = 0, 1, 2, 3
+    sd.materials = [host.diffuse(sp.rgb_albedo((0.73, 0.73, 0.73))), host.diffuse(sp.rgb_albedo((0.63, 0.065, 0.05))),
+                    host.diffuse(sp.rgb_albedo((0.14, 0.45, 0.091))), host.dielectric(host.constant_spectrum(1.5))]
+    verts, tris, mats = [], [], []
+
+    def quad(a, b, c, d, m):
+        i = len(verts)
+        verts.extend([a, b, c, d])
+        tris.extend([[i, i + 1, i + 2], [i, i + 2, i + 3]])
+        mats.extend([m, m])
+
+    def box(lo, hi, angle_deg, m):
+        cx, cz = (lo[0] + hi[0]) / 2, (lo[2] + hi[2]) / 2
+        ca, sa = np.cos(np.radians(angle_deg)), np.sin(np.radians(angle_deg))
+
+        def P(x, y, z):
+            dx, dz = x - cx, z - cz
+            return [cx + ca * dx + sa * dz, y, cz - sa * dx + ca * dz]
+        x0, y0, z0 = lo
+        x1, y1, z1 = hi
+        quad(P(x0, y0, z1), P(x1, y0, z1), P(x1, y1, z1), P(x0, y1, z1), m)
+        quad(P(x1, y0, z0), P(x0, y0, z0), P(x0, y1, z0), P(x1, y1, z0), m)
+        quad(P(x0, y0, z0), P(x0, y0, z1), P(x0, y1, z1), P(x0, y1, z0), m)
+        quad(P(x1, y0, z1), P(x1, y0, z0), P(x1, y1, z0), P(x1, y1, z1), m)
+        quad(P(x0, y1, z1), P(x1, y1, z1), P(x1, y1, z0), P(x0, y1, z0), m)
+        quad(P(x0, y0, z0), P(x1, y0, z0), P(x1, y0, z1), P(x0, y0, z1), m)
+
+    quad([-1, -1, -1], [1, -1, -1], [1, -1, 1], [-1, -1, 1], white)     # floor
+    quad([-1, 1, -1], [-1, 1, 1], [1, 1, 1], [1, 1, -1], white)        # ceiling
+    quad([-1, -1, -1], [-1, 1, -1], [1, 1, -1], [1, -1, -1], white)    # back
+    quad([-1, -1, -1], [-1, -1, 1], [-1, 1, 1], [-1, 1, -1], red)      # left
+    quad([1, -1, -1], [1, 1, -1], [1, 1, 1], [1, -1, 1], green)        # right
+    box((-0.7, -1.0, -0.65), (-0.1, 0.2, -0.05), 17.0, white)           # tall box
+    box((0.1, -1.0, 0.0), (0.7, -0.4, 0.6), -18.0, white)               # short box
+    pos = _xf_points(rfw.m, np.asarray(verts, f32))
+    sd.prims = [TriangleMesh(pos, np.asarray(tris, np.uint32))]
+    sd.prim_materials = list(mats)
+    if glass_sphere:
+        t = rfw * host.Transform.translate((0.4, -0.1, 0.3))
+        sd.prims.append(Sphere(0.3, -0.3, 0.3, 360.0, t.m, t.m_inv, False))
+        sd.prim_materials.append(glass)
+    lt = rfw * host.Transform.translate((0.0, 0.9, 0.0))
+    table = sp.d65.copy()
+    sd.lights = [host.light(host.PM_LIGHT_POINT, table, f32(4.0) / f32(sp.photometric(table)), lt.m)]
+    return sd
