@@ -5,10 +5,14 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 laun
 torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
 
 Workloads (BASELINE.json configs):
-  trace   C3: ~1M-triangle synthetic mesh, 4096x4096 primary rays, closest-hit (metric: Mrays/s)
-A step = one pass of the hot path over one batch of synthetic rays that is already resident in HBM.
-Rays shard across ranks with no data-path collective (every rank traces its own batch against its own
-replica of the BVH) => weak scaling.
+  path    C2 (default, BASELINE.json configs[1]): Cornell box, SimplePathIntegrator(max_depth 5, NEE, BSDF sampling),
+          1024x1024 @ 64 spp per GPU.  A step = one whole Integrate::render() of the image plus — for N>1 — the
+          film merge.  Metric: path samples/s.  N>1: sample split (rank r renders sample indices [64r, 64(r+1)) of a
+          64*N-spp image), films merged by ONE RCCL all-reduce of the f64 film per step => weak scaling.
+          The C3 closest-hit figure is measured in the same run and reported under "closest_hit".
+  trace   C3: 1,048,576-triangle synthetic mesh, 4096x4096 primary rays per GPU, closest hit.  Metric: Mrays/s.
+          Rays shard across ranks with no collective (every rank owns a replica of the BVH) => weak scaling.
+Inputs (scene, BVH, rays) are resident in HBM before the timed region starts.
 
 The oracle (oracle/) is used ONLY for the cpu_baseline leg, on rank 0 at N=1.
 """
@@ -25,26 +29,36 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+KERNEL_NAMES = ["raygen_kernel", "closest_kernel", "shade_kernel", "shadow_kernel", "accumulate_kernel"]
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="trace", choices=["trace"])
-    ap.add_argument("--res", type=int, default=4096, help="primary-ray image side (trace workload)")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="path", choices=["path", "trace"])
+    ap.add_argument("--res", type=int, default=None, help="image side (path: 1024, trace: 4096)")
+    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per GPU (path workload)")
+    ap.add_argument("--max-depth", type=int, default=5)
     ap.add_argument("--blobs", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 21, help="rays in the bounded CPU-baseline sample")
+    ap.add_argument("--no-secondary", action="store_true", help="path workload: skip the C3 closest-hit figure")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 21, help="rays in the bounded CPU-baseline sample (trace)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time bound (path)")
     return ap.parse_args()
+
+
+def _oracle():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as ora
+    return ora
 
 
 def cpu_baseline_trace(pos, idx, rays_sample, threads):
     """C++ restatement of the pbrt-rs CPU path (binary 64-B-node BVH, Middle split as in main.rs:217-221,
     per-node divides, per-ray heap stack) timed on this box's host cores."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as ora
+    ora = _oracle()
     sc = ora.Scene()
     sc.add_triangle_mesh(pos, idx)
     t0 = time.time()
@@ -57,6 +71,176 @@ def cpu_baseline_trace(pos, idx, rays_sample, threads):
             "sample": f"first {len(rays_sample)} primary rays of the same batch, closest hit; "
                       f"binary-BVH build {build_s:.1f}s not included",
             "nodes_per_ray": ctr["nodes_visited"] / len(rays_sample), "prims_per_ray": ctr["prims_tested"] / len(rays_sample)}
+
+
+def cpu_baseline_path(pm, sd, spp, max_depth, threads, seconds):
+    """The oracle's Integrate::render() (row-parallel like the reference's rayon loop, base.rs:50-63) on a bounded
+    sample of the same workload: the same image, one sample index (one sample of every pixel) at a time, until
+    `seconds` have elapsed."""
+    ora = _oracle()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    oren = helpers.oracle_renderer_from(sd, ora)
+    x0, y0, x1, y1 = sd.film["pixel_bounds"]
+    band = (x0, y0, x1, y1)
+    n, s, t0 = 0, 0, time.time()
+    while s < spp and time.time() - t0 < seconds:
+        p = helpers.render_params(pm, sd, spp, max_depth, True, True, 0, window=band, samples=(s, s + 1))
+        n += oren.render(p, threads)["samples"]
+        s += 1
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"rows {band[1]}..{band[3]} of the same {x1 - x0}x{y1 - y0} image, sample indices 0..{s} "
+                      f"({n} path samples, {dt:.1f} s)"}
+
+
+def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, want_cpu):
+    res = args.res or 4096
+    pos, idx = pm.scenes.blob_mesh(args.blobs, 1024, seed=1)
+    agg = pm.GpuAggregate([pm.TriangleMesh(pos, idx)], device_id=local_rank)
+    rays = pm.scenes.primary_rays(res, res, eye=(0.02 * rank, 0.0, -4.0))
+    n_rays = len(rays)
+    d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
+    d_hits = torch.empty((n_rays, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    # deterministic traversal counters (untimed pass with the counting kernel) -> algorithmic bytes
+    agg.set_counting(True)
+    agg.reset_counters()
+    agg.intersect(d_rays, out=d_hits)
+    ctr = agg.counters()
+    agg.set_counting(False)
+    n_node, n_prim = ctr["nodes_visited"] / n_rays, ctr["prims_tested"] / n_rays
+    s_node, s_prim = agg.info.node_bytes, agg.info.prim_record_bytes[2]
+    bytes_per_ray = 32 + 16 + n_node * s_node + n_prim * s_prim
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        agg.intersect(d_rays, out=d_hits)
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        agg.intersect(d_rays, out=d_hits)      # blocking: returns after the library's stream has drained
+        kernel_ms.append(agg.last_kernel_ms())
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    hit_frac = float((d_hits[:, 0].view(torch.int32) != -1).float().mean().item())
+    k_ms = float(np.mean(kernel_ms))
+    achieved = bytes_per_ray * n_rays / (k_ms * 1e-3) / 1e9
+    out = {
+        "metric": "closest-hit Mrays/s", "value": n_rays * world * steps / dt / 1e6, "unit": "Mrays/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C3 closest-hit microbench: {len(idx)} triangles ({args.blobs} blobs x 1024), "
+                               f"{res}x{res} primary rays per GPU in 8x8 tile order",
+                   "rays_per_gpu": n_rays, "hit_fraction": hit_frac, "bvh_nodes": int(agg.info.n_nodes),
+                   "bvh_node_bytes": int(s_node), "tri_record_bytes": int(s_prim)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "trace_kernel<false,false>", "kernel_ms": k_ms,
+                     "bytes_per_ray": bytes_per_ray, "nodes_per_ray": n_node, "prims_per_ray": n_prim},
+    }
+    if want_cpu and rank == 0:
+        threads = min(16, len(os.sched_getaffinity(0)))
+        out["cpu_baseline"] = cpu_baseline_trace(pos, idx, rays[:args.cpu_sample], threads)
+    del agg
+    return out
+
+
+def kernel_bytes(st, info, sd):
+    """Algorithmic HBM bytes of one render() per kernel class: structure-of-arrays path state that each
+    kernel must read/write once per item + BVH node/leaf-record bytes from the traversal counters."""
+    rec = info.prim_buffer_bytes / max(1, info.n_prims)     # mean leaf-record size of this scene
+    node = info.node_bytes
+    S, C, SH = st["samples"], st["closest_rays"], st["shadow_rays"]
+    shaded = C                       # one shade item per closest-hit ray
+    b = [0.0] * 5
+    b[0] = S * (7 * 16 + 8)                                          # ray_o ray_d beta L lambda pdf rng + misc
+    b[1] = C * (4 + 8 + 32 + 16) + st["closest_nodes"] * node + st["closest_prims"] * rec
+    b[2] = shaded * (4 + 8 + 16 + 16 + 16 + 16 + 16 + 32 + 32)       # queue misc hit beta L lambda pdf ray rng(r+w)
+    b[2] += (C - S) * (32 + 16 + 8 + 4) + SH * (48 + 4) + shaded * 72   # continuation + shadow-ray writes + shading record
+    b[3] = SH * (4 + 32) + st["shadow_nodes"] * node + st["shadow_prims"] * rec + SH * 48
+    b[4] = S * (48 + 8) + (S / max(1, st["spp_rendered"])) * 64
+    return b
+
+
+def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup):
+    res = args.res or 1024
+    spp_total = args.spp * world
+    sd = pm.scenes.cornell_scene((res, res))
+    integ = pm.WavefrontIntegrator(args.max_depth, True, True, sd, spp_total, seed=0, device_id=local_rank)
+    s0, s1 = pm.distributed.shard_samples(spp_total, rank, world)
+    film = torch.empty((res, res, 4), dtype=torch.float64, device="cuda")
+
+    def step():
+        integ.clear()
+        st = integ.render(samples=(s0, s1))
+        if world > 1:
+            integ.film(out=film)
+            pm.distributed.allreduce_film(film)
+        return st
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed counting pass -> algorithmic bytes per kernel class
+    integ.aggregate.set_counting(True)
+    st_c = step()
+    integ.aggregate.set_counting(False)
+    st_c["spp_rendered"] = s1 - s0
+    bytes_k = kernel_bytes(st_c, integ.aggregate.info, sd)
+    for _ in range(warmup):
+        step()
+    barrier()
+    ms_k = np.zeros(5)
+    launches = np.zeros(5)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st = step()
+        ms_k += np.asarray(st["ms_by_kernel"])
+        launches += np.asarray(st["launches_by_kernel"])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_k /= steps
+    launches /= steps
+    samples = st["samples"]
+    dom = int(np.argmax(ms_k))
+    achieved = bytes_k[dom] / (ms_k[dom] * 1e-3) / 1e9
+    total_bytes = float(sum(bytes_k))
+    out = {
+        "metric": "path samples/s", "value": samples * world * steps / dt, "unit": "samples/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C2 Cornell box path tracing: {res}x{res} @ {args.spp} spp per GPU, SimplePathIntegrator "
+                               f"max_depth {args.max_depth}, light + BSDF sampling, Gaussian filter, 4 wavelengths/sample",
+                   "samples_per_gpu": samples, "closest_rays": st["closest_rays"], "shadow_rays": st["shadow_rays"],
+                   "passes": st["passes"], "merge": "none" if world == 1 else "RCCL all-reduce of the f64 film per step",
+                   "bytes_per_sample": total_bytes / samples,
+                   "kernel_ms": dict(zip(KERNEL_NAMES, [float(x) for x in ms_k])),
+                   "kernel_GBps": dict(zip(KERNEL_NAMES, [float(b / (m * 1e-3) / 1e9) if m > 0 else 0.0
+                                                          for b, m in zip(bytes_k, ms_k)]))},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": KERNEL_NAMES[dom],
+                     "kernel_ms": float(ms_k[dom] / max(1.0, launches[dom])), "launches_per_step": float(launches[dom]),
+                     "bytes_per_launch": bytes_k[dom] / max(1.0, launches[dom]),
+                     "whole_render": {"achieved": total_bytes / (float(ms_k.sum()) * 1e-3) / 1e9,
+                                      "frac": total_bytes / (float(ms_k.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+    }
+    return out, sd, integ
 
 
 def main():
@@ -72,71 +256,24 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     pm = importlib.import_module("pbrt-rs_amd")
+    want_cpu = world == 1 and not args.no_cpu_baseline
 
-    # ---- synthetic scene + rays (same geometry on every rank; rank-dependent camera offset so batches differ)
-    pos, idx = pm.scenes.blob_mesh(args.blobs, 1024, seed=1)
-    agg = pm.GpuAggregate([pm.TriangleMesh(pos, idx)], device_id=local_rank)
-    rays = pm.scenes.primary_rays(args.res, args.res, eye=(0.02 * rank, 0.0, -4.0))
-    n_rays = len(rays)
-    d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
-    d_hits = torch.empty((n_rays, 4), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
-
-    # ---- deterministic traversal counters (untimed pass with the counting kernel) -> algorithmic bytes
-    agg.set_counting(True)
-    agg.reset_counters()
-    agg.intersect(d_rays, out=d_hits)
-    ctr = agg.counters()
-    agg.set_counting(False)
-    n_node = ctr["nodes_visited"] / n_rays
-    n_prim = ctr["prims_tested"] / n_rays
-    s_node = agg.info.node_bytes
-    s_prim = agg.info.prim_record_bytes[2]
-    bytes_per_ray = 32 + 16 + n_node * s_node + n_prim * s_prim
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        agg.intersect(d_rays, out=d_hits)
-    barrier()
-    kernel_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        agg.intersect(d_rays, out=d_hits)      # blocking: returns after the library's stream has drained
-        kernel_ms.append(agg.last_kernel_ms())
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    hit_frac = float((d_hits[:, 0].view(torch.int32) != -1).float().mean().item())
-
-    if rank == 0:
-        value = n_rays * world * args.steps / dt / 1e6
-        k_ms = float(np.mean(kernel_ms))
-        achieved = bytes_per_ray * n_rays / (k_ms * 1e-3) / 1e9
-        out = {
-            "metric": "closest-hit Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C3 closest-hit microbench: {len(idx)} triangles ({args.blobs} blobs x 1024), "
-                                   f"{args.res}x{args.res} primary rays per GPU in 8x8 tile order",
-                       "rays_per_gpu": n_rays, "hit_fraction": hit_frac, "bvh_nodes": int(agg.info.n_nodes),
-                       "bvh_node_bytes": int(s_node), "tri_record_bytes": int(s_prim)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "trace_kernel<false,false>", "kernel_ms": k_ms,
-                         "bytes_per_ray": bytes_per_ray, "nodes_per_ray": n_node, "prims_per_ray": n_prim},
-        }
-        if world == 1 and not args.no_cpu_baseline:
+    if args.workload == "trace":
+        out = run_trace(args, pm, torch, dist, rank, local_rank, world, args.steps, args.warmup, want_cpu)
+    else:
+        out, sd, integ = run_path(args, pm, torch, dist, rank, local_rank, world, args.steps, args.warmup)
+        if want_cpu and rank == 0:
             threads = min(16, len(os.sched_getaffinity(0)))
-            out["cpu_baseline"] = cpu_baseline_trace(pos, idx, rays[:args.cpu_sample], threads)
+            out["cpu_baseline"] = cpu_baseline_path(pm, sd, args.spp, args.max_depth, threads, args.cpu_seconds)
+        del integ
+        if not args.no_secondary:
+            tr = run_trace(args, pm, torch, dist, rank, local_rank, world, max(3, args.steps), 1, False)
+            out["closest_hit"] = {"value": tr["value"], "unit": tr["unit"], "workload": tr["config"]["workload"],
+                                  "ms_per_step": tr["ms_per_step"], "roofline": tr["roofline"]}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

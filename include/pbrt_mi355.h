@@ -178,6 +178,11 @@ typedef struct PmRenderStats {
     uint64_t passes, kernels_launched;
     double kernel_ms;          /* device time of all kernels of the last pm_render (HIP events) */
     double state_bytes_per_path;
+    /* per kernel class: 0 raygen, 1 closest_hit, 2 shade, 3 shadow (any-hit), 4 accumulate */
+    double ms_by_kernel[5];
+    uint64_t launches_by_kernel[5];
+    /* traversal counters of this render (only with pm_set_counting(ctx, 1)) */
+    uint64_t closest_nodes, closest_prims, shadow_nodes, shadow_prims;
 } PmRenderStats;
 
 int pm_set_materials(pm_ctx* ctx, const PmMaterial* mats, uint32_t n);

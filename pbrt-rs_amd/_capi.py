@@ -75,7 +75,9 @@ class PmRenderParams(C.Structure):
 class PmRenderStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("passes", C.c_uint64), ("kernels_launched", C.c_uint64), ("kernel_ms", C.c_double),
-                ("state_bytes_per_path", C.c_double)]
+                ("state_bytes_per_path", C.c_double), ("ms_by_kernel", C.c_double * 5),
+                ("launches_by_kernel", C.c_uint64 * 5), ("closest_nodes", C.c_uint64), ("closest_prims", C.c_uint64),
+                ("shadow_nodes", C.c_uint64), ("shadow_prims", C.c_uint64)]
 
 
 PM_SPEC_CONSTANT, PM_SPEC_DENSE, PM_SPEC_RGB_ALBEDO, PM_SPEC_RGB_UNBOUNDED, PM_SPEC_RGB_ILLUMINANT, PM_SPEC_BLACKBODY = range(6)

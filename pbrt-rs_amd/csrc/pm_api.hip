@@ -61,8 +61,8 @@ extern "C" int pm_create(int device_id, pm_ctx** out) {
     c->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipMalloc(&c->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(c->d_counters, 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
         delete c;
         return PM_ERR_HIP;
     }
@@ -274,7 +274,7 @@ extern "C" int pm_set_counting(pm_ctx* c, int enabled) { if (!c) return PM_ERR_I
 extern "C" int pm_reset_counters(pm_ctx* c) {
     if (!c || c->device < 0) return PM_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemset(c->d_counters, 0, 4 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long)));
     c->rays_counted = 0;
     return PM_OK;
 }

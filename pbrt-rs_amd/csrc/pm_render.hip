@@ -90,8 +90,9 @@ __global__ __launch_bounds__(RB) void raygen_kernel(RenderConst rc, SceneArrays 
 }
 
 // ------------------------------------------------------------------------------------------ traversal
+template <bool COUNT>
 __global__ __launch_bounds__(TB) void closest_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
-                                                     const uint32_t* __restrict__ count) {
+                                                     const uint32_t* __restrict__ count, unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
     const uint32_t i = xcd_remap_r(blockIdx.x, gridDim.x) * TB + threadIdx.x;
     if (i >= *count) return;
@@ -100,10 +101,14 @@ __global__ __launch_bounds__(TB) void closest_kernel(SceneArrays sc, PathArrays 
     const float4 o = pa.ray_o[slot], d = pa.ray_d[slot];
     Ray ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(d.x, d.y, d.z); ray.tmax = INFINITY;
     HitRec h; TravCounters tc = {0u, 0u, 0u};
-    traverse<false, false>(sc.nodes, sc.prims, ray, &h, stack + threadIdx.x, TB, &tc);
+    traverse<false, COUNT>(sc.nodes, sc.prims, ray, &h, stack + threadIdx.x, TB, &tc);
     pa.hit[slot] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
+    if (COUNT) { atomicAdd(&counters[1], (unsigned long long)tc.nodes); atomicAdd(&counters[2], (unsigned long long)tc.prims); }
+    if (tc.overflow) atomicAdd(&counters[3], 1ull);
 }
-__global__ __launch_bounds__(TB) void shadow_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ count) {
+template <bool COUNT>
+__global__ __launch_bounds__(TB) void shadow_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ count,
+                                                    unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
     const uint32_t i = xcd_remap_r(blockIdx.x, gridDim.x) * TB + threadIdx.x;
     if (i >= *count) return;
@@ -111,7 +116,9 @@ __global__ __launch_bounds__(TB) void shadow_kernel(SceneArrays sc, PathArrays p
     const float4 o = pa.sh_o[slot], d = pa.sh_d[slot];
     Ray ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(d.x, d.y, d.z); ray.tmax = o.w;
     HitRec h; TravCounters tc = {0u, 0u, 0u};
-    const bool occluded = traverse<true, false>(sc.nodes, sc.prims, ray, &h, stack + threadIdx.x, TB, &tc);
+    const bool occluded = traverse<true, COUNT>(sc.nodes, sc.prims, ray, &h, stack + threadIdx.x, TB, &tc);
+    if (COUNT) { atomicAdd(&counters[4], (unsigned long long)tc.nodes); atomicAdd(&counters[5], (unsigned long long)tc.prims); }
+    if (tc.overflow) atomicAdd(&counters[3], 1ull);
     if (!occluded) {
         float4 L = pa.L[slot];
         const float4 c = pa.sh_L[slot];
@@ -377,12 +384,14 @@ struct RenderState {
     PathArrays pa{}; size_t pa_cap = 0; int pa_depth = 0;
     std::vector<void*> pa_allocs;
     PmRenderStats stats{};
+    std::vector<hipEvent_t> ev_pool;      // per-launch timing: one event before every kernel of a pass + one after
 };
 
 void pm_render_state_destroy(pm_ctx* c) {
     RenderState* r = c->render;
     if (!r) return;
     for (void* p : r->pa_allocs) (void)hipFree(p);
+    for (hipEvent_t e : r->ev_pool) (void)hipEventDestroy(e);
     void* ptrs[] = {r->d_pool, r->d_mats, r->d_lights, r->d_inf, r->d_prim_mat, r->d_prim_ref, r->d_patches, r->d_spheres, r->d_m9, r->d_film};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete r;
@@ -667,28 +676,50 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     PathArrays& pa = r->pa;
     const int nb = p->max_depth + 2;
     std::vector<uint32_t> hcounts(2 * (size_t)nb);
+    const size_t max_launch = 3 * (size_t)(p->max_depth + 1) + 3;
+    while (r->ev_pool.size() < max_launch + 1) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); r->ev_pool.push_back(e); }
+    std::vector<int> ev_class; ev_class.reserve(max_launch);
+    auto mark = [&](int cls) { (void)hipEventRecord(r->ev_pool[ev_class.size()], c->stream); ev_class.push_back(cls); };
+    unsigned long long cnt_before[6] = {0, 0, 0, 0, 0, 0};
+    HIPCHK(c, hipMemcpy(cnt_before, c->d_counters, sizeof(cnt_before), hipMemcpyDeviceToHost));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     for (int sb = s0; sb < s1; sb += s_per_pass) {
+        ev_class.clear();
         rc.s_base = sb; rc.s_count = std::min(s_per_pass, s1 - sb);
         const uint32_t npaths = (uint32_t)(npix_pad * (size_t)rc.s_count);
         HIPCHK(c, hipMemsetAsync(pa.counts, 0, 2 * (size_t)nb * 4, c->stream));
         const dim3 gr((npaths + RB - 1) / RB), gt((npaths + TB - 1) / TB);
+        mark(0);
         hipLaunchKernelGGL(raygen_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, npaths);
         uint32_t *qin = pa.q0, *qout = pa.q1;
         for (int b = 0; b <= p->max_depth; ++b) {
             uint32_t* cnt_in = pa.counts + b; uint32_t* cnt_out = pa.counts + b + 1; uint32_t* cnt_sh = pa.counts + nb + b;
-            hipLaunchKernelGGL(closest_kernel, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in);
+            mark(1);
+            if (c->counting) hipLaunchKernelGGL(closest_kernel<true>, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_counters);
+            else hipLaunchKernelGGL(closest_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_counters);
+            mark(2);
             hipLaunchKernelGGL(shade_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, qin, cnt_in, qout, cnt_out, cnt_sh);
-            if (p->sample_lights && b < p->max_depth)
-                hipLaunchKernelGGL(shadow_kernel, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh);
+            if (p->sample_lights && b < p->max_depth) {
+                mark(3);
+                if (c->counting) hipLaunchKernelGGL(shadow_kernel<true>, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_counters);
+                else hipLaunchKernelGGL(shadow_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_counters);
+            }
             std::swap(qin, qout);
             r->stats.kernels_launched += 3;
         }
+        if (!debug_one) mark(4);
         if (!debug_one)
             hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((npix_pad + RB - 1) / RB)), dim3(RB), 0, c->stream, rc, sa, pa, r->d_film);
         HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(r->ev_pool[ev_class.size()], c->stream));
         HIPCHK(c, hipMemcpyAsync(hcounts.data(), pa.counts, hcounts.size() * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (size_t e = 0; e < ev_class.size(); ++e) {
+            float ems = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ems, r->ev_pool[e], r->ev_pool[e + 1]));
+            r->stats.ms_by_kernel[ev_class[e]] += ems;
+            r->stats.launches_by_kernel[ev_class[e]] += 1;
+        }
         r->stats.passes++;
         r->stats.samples += (uint64_t)W * H * rc.s_count;
         // closest rays: every live path in the queue of bounce b (padded slots are not live)
@@ -701,6 +732,13 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     r->stats.kernel_ms = ms; c->last_ms = ms;
+    {
+        unsigned long long cnt_after[6];
+        HIPCHK(c, hipMemcpy(cnt_after, c->d_counters, sizeof(cnt_after), hipMemcpyDeviceToHost));
+        r->stats.closest_nodes = cnt_after[1] - cnt_before[1]; r->stats.closest_prims = cnt_after[2] - cnt_before[2];
+        r->stats.shadow_nodes = cnt_after[4] - cnt_before[4]; r->stats.shadow_prims = cnt_after[5] - cnt_before[5];
+        if (cnt_after[3] != cnt_before[3]) return fail(c, PM_ERR_STACK_OVERFLOW, "pm_render: traversal stack overflow");
+    }
     if (debug_one) {
         float4 h[3]; uint2 m;
         HIPCHK(c, hipMemcpy(&h[0], pa.L, 16, hipMemcpyDeviceToHost));

@@ -80,7 +80,11 @@ class WavefrontIntegrator:
     def stats(self):
         s = PmRenderStats()
         self.aggregate._check(self._lib.pm_get_render_stats(self._h, C.byref(s)))
-        return {k: getattr(s, k) for k, _ in PmRenderStats._fields_}
+        out = {}
+        for k, _ in PmRenderStats._fields_:
+            v = getattr(s, k)
+            out[k] = list(v) if hasattr(v, "__len__") else v
+        return out
 
     def debug_sample(self, px, py, sample_index):
         """(L[4], lambda[4], pdf[4], filter_weight) of one (pixel, sample) — test hook."""
