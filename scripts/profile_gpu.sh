@@ -1,0 +1,25 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + PMC passes for bench.py; output under gpurun_out/prof/.
+# Each profiler run is its own process under a time limit; PMC passes never combine with trace domains other than kernel-trace.
+set -u
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof
+mkdir -p $OUT
+cd $R
+step() { echo "== $*" >> $OUT/progress.log; }
+step stats-path
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_path -o path --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/stats_path.log 2>&1 || exit 1
+step stats-trace
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_trace -o trace --output-format csv -- python3 bench.py --workload trace --steps 5 --warmup 1 --no-cpu-baseline > $OUT/stats_trace.log 2>&1 || exit 1
+for W in path trace; do
+  if [ $W = path ]; then ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-secondary"; else ARGS="--workload trace --steps 1 --warmup 0 --no-cpu-baseline"; fi
+  step pmc-fetch-$W
+  timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum -d $OUT/pmc_fetch_$W -o f --output-format csv -- python3 bench.py $ARGS > $OUT/pmc_fetch_$W.log 2>&1 || exit 1
+  step pmc-write-$W
+  timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d $OUT/pmc_write_$W -o w --output-format csv -- python3 bench.py $ARGS > $OUT/pmc_write_$W.log 2>&1 || exit 1
+  step pmc-sq-$W
+  timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $OUT/pmc_sq_$W -o s --output-format csv -- python3 bench.py $ARGS > $OUT/pmc_sq_$W.log 2>&1 || exit 1
+done
+step done
+ls -R $OUT | head -60 >> $OUT/progress.log
