@@ -230,6 +230,10 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup):
                    "samples_per_gpu": samples, "closest_rays": st["closest_rays"], "shadow_rays": st["shadow_rays"],
                    "passes": st["passes"], "merge": "none" if world == 1 else "RCCL all-reduce of the f64 film per step",
                    "bytes_per_sample": total_bytes / samples,
+                   "closest_nodes_per_ray": st_c["closest_nodes"] / max(1, st_c["closest_rays"]),
+                   "closest_prims_per_ray": st_c["closest_prims"] / max(1, st_c["closest_rays"]),
+                   "shadow_nodes_per_ray": st_c["shadow_nodes"] / max(1, st_c["shadow_rays"]),
+                   "shadow_prims_per_ray": st_c["shadow_prims"] / max(1, st_c["shadow_rays"]),
                    "kernel_ms": dict(zip(KERNEL_NAMES, [float(x) for x in ms_k])),
                    "kernel_GBps": dict(zip(KERNEL_NAMES, [float(b / (m * 1e-3) / 1e9) if m > 0 else 0.0
                                                           for b, m in zip(bytes_k, ms_k)]))},

@@ -66,6 +66,8 @@ typedef struct PmAccelInfo {
 /* deterministic traversal counters: totals since pm_reset_counters */
 typedef struct PmCounters {
     uint64_t rays, nodes_visited, prims_tested, stack_overflows;
+    uint64_t exact_tests;      /* reference-arithmetic primitive tests actually run (prims_tested counts pre-filter tests too) */
+    uint64_t fallback_walks;   /* rays re-walked with immediate exact tests because culling was not confirmed (expected 0) */
 } PmCounters;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

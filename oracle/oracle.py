@@ -122,10 +122,11 @@ def wide_trace(node_buf, prim_buf, rays, any_hit=False, nthreads=8):
     """Walk the GPU-layout tree on the CPU; returns (hits or occlusion, counters)."""
     assert rays.dtype == RAY_DTYPE
     out = np.empty(len(rays), np.uint8 if any_hit else HIT_DTYPE)
-    ctr = np.zeros(2, np.uint64)
+    ctr = np.zeros(4, np.uint64)
     lib().ora_wide_trace(node_buf.ctypes.data, prim_buf.ctypes.data, rays.ctypes.data, len(rays), out.ctypes.data,
                          int(any_hit), ctr.ctypes.data, nthreads)
-    return out, {"nodes_visited": int(ctr[0]), "prims_tested": int(ctr[1])}
+    return out, {"nodes_visited": int(ctr[0]), "prims_tested": int(ctr[1]), "exact_tests": int(ctr[2]),
+                 "fallback_walks": int(ctr[3])}
 
 
 class Renderer:

@@ -139,7 +139,7 @@ void ora_trace_any(OraScene* s, const OraRay* rays, uint64_t n, uint8_t* out, ui
 
 // Walk the GPU-layout wide BVH on the CPU (same order as the HIP kernel).  any_hit: out is uint8[n], else OraHit[n].
 void ora_wide_trace(const void* nodes, const void* prims, const OraRay* rays, uint64_t n, void* out, int any_hit,
-                    uint64_t* counters2, int nthreads) {
+                    uint64_t* counters4, int nthreads) {
     WideWalker ww{reinterpret_cast<const WNode*>(nodes), reinterpret_cast<const uint8_t*>(prims)};
     std::vector<Counters> ctr(std::max(1, nthreads));
     parallel_chunks(n, nthreads, [&](uint64_t b, uint64_t e, int tid) {
@@ -151,10 +151,94 @@ void ora_wide_trace(const void* nodes, const void* prims, const OraRay* rays, ui
             else { OraHit& h = reinterpret_cast<OraHit*>(out)[i]; h.prim_id = id; h.t = t; h.u = u; h.v = v; }
         }
     });
-    if (counters2) {
-        counters2[0] = counters2[1] = 0;
-        for (auto& c : ctr) { counters2[0] += c.nodes_visited; counters2[1] += c.prims_tested; }
+    if (counters4) {
+        counters4[0] = counters4[1] = counters4[2] = counters4[3] = 0;
+        for (auto& c : ctr) {
+            counters4[0] += c.nodes_visited; counters4[1] += c.prims_tested; counters4[2] += c.exact_tests; counters4[3] += c.fallback_walks;
+        }
     }
+}
+
+// Lock-step model of one 64-lane wave running the kernel's loop over 64 consecutive rays: iteration i of the wave costs a
+// node step if any lane does one, plus max-over-lanes primitive (pre-filter) tests.  out6 = {waves, wave iterations,
+// wave node steps, wave prim trips, lane node steps, lane prim tests}.  Analysis tool only.
+void ora_wide_wave_model(const void* nodes, const void* prims, const OraRay* rays, uint64_t n, int any_hit, uint64_t* out6, int nthreads) {
+    WideWalker ww{reinterpret_cast<const WNode*>(nodes), reinterpret_cast<const uint8_t*>(prims)};
+    const uint64_t nw = (n + 63) / 64;
+    std::vector<std::array<uint64_t, 6>> acc(std::max(1, nthreads), std::array<uint64_t, 6>{0, 0, 0, 0, 0, 0});
+    parallel_chunks(nw, nthreads, [&](uint64_t b, uint64_t e, int tid) {
+        std::vector<std::vector<uint8_t>> tr(64);
+        for (uint64_t w = b; w < e; ++w) {
+            size_t maxlen = 0;
+            for (int l = 0; l < 64; ++l) {
+                tr[l].clear();
+                uint64_t i = w * 64 + l;
+                if (i >= n) continue;
+                const OraRay& r = rays[i];
+                uint32_t id; float t, u, v;
+                ww.walk(V3(r.o[0], r.o[1], r.o[2]), V3(r.d[0], r.d[1], r.d[2]), r.tmax, any_hit != 0, &id, &t, &u, &v, nullptr, &tr[l]);
+                maxlen = std::max(maxlen, tr[l].size());
+            }
+            auto& a = acc[tid];
+            a[0]++; a[1] += maxlen;
+            for (size_t it = 0; it < maxlen; ++it) {
+                bool node = false; uint32_t mp = 0;
+                for (int l = 0; l < 64; ++l) {
+                    if (it >= tr[l].size()) continue;
+                    uint8_t x = tr[l][it];
+                    if (x != 255) { node = true; mp = std::max<uint32_t>(mp, x); a[4]++; a[5] += x; }
+                }
+                if (node) a[2]++;
+                a[3] += mp;
+            }
+        }
+    });
+    for (int k = 0; k < 6; ++k) { out6[k] = 0; for (auto& a : acc) out6[k] += a[k]; }
+}
+
+// Same model for PERSISTENT waves with batch refill: `n_waves` waves pull consecutive ray indices from one global counter;
+// a wave refills its idle lanes when at least `thresh` of them are idle (or all are).  Pops are merged into the node step
+// when merge_pop != 0.  out6 = {refills, wave iterations, wave node steps, wave prim trips, lane node steps, lane prim tests}.
+void ora_wide_wave_model_persistent(const void* nodes, const void* prims, const OraRay* rays, uint64_t n, int any_hit,
+                                    int n_waves, int thresh, int merge_pop, uint64_t* out6) {
+    WideWalker ww{reinterpret_cast<const WNode*>(nodes), reinterpret_cast<const uint8_t*>(prims)};
+    struct Lane { std::vector<uint8_t> tr; size_t pos = 0; bool active = false; };
+    std::vector<std::vector<Lane>> waves(n_waves, std::vector<Lane>(64));
+    uint64_t next = 0;
+    uint64_t a[6] = {0, 0, 0, 0, 0, 0};
+    bool any_active = true;
+    while (any_active) {
+        any_active = false;
+        for (auto& wv : waves) {
+            int idle = 0;
+            for (auto& l : wv) if (!l.active) idle++;
+            if ((idle >= thresh || idle == 64) && next < n) {
+                a[0]++;
+                for (auto& l : wv) {
+                    if (l.active || next >= n) continue;
+                    const OraRay& r = rays[next++];
+                    uint32_t id; float t, u, v;
+                    l.tr.clear(); l.pos = 0;
+                    ww.walk(V3(r.o[0], r.o[1], r.o[2]), V3(r.d[0], r.d[1], r.d[2]), r.tmax, any_hit != 0, &id, &t, &u, &v, nullptr, &l.tr);
+                    if (merge_pop) { size_t k = 0; for (uint8_t x : l.tr) if (x != 255) l.tr[k++] = x; l.tr.resize(k); }
+                    l.active = !l.tr.empty();
+                }
+            }
+            bool node = false, act = false; uint32_t mp = 0;
+            for (auto& l : wv) {
+                if (!l.active) continue;
+                act = true;
+                uint8_t x = l.tr[l.pos++];
+                if (x != 255) { node = true; mp = std::max<uint32_t>(mp, x); a[4]++; a[5] += x; }
+                if (l.pos >= l.tr.size()) l.active = false;
+            }
+            if (act) { a[1]++; any_active = true; }
+            if (node) a[2]++;
+            a[3] += mp;
+        }
+        if (next < n) any_active = true;
+    }
+    for (int k = 0; k < 6; ++k) out6[k] = a[k];
 }
 
 // ---- Integrate::render() on the CPU, from the flattened scene (same struct layouts as include/pbrt_mi355.h) ----

@@ -193,7 +193,7 @@ struct LinearNode {      // aggregates.rs:719-732
     uint32_t second_child; uint8_t axis;          // interior
 };
 
-struct Counters { uint64_t nodes_visited = 0, prims_tested = 0; };
+struct Counters { uint64_t nodes_visited = 0, prims_tested = 0, exact_tests = 0, fallback_walks = 0; };
 
 enum SplitMethod { SPLIT_SAH = 1, SPLIT_MIDDLE = 2, SPLIT_EQUAL_COUNTS = 3 };
 

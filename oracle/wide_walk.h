@@ -60,62 +60,141 @@ struct WideWalker {
         }
     }
 
-    // returns true if something was hit; closest-hit unless any_hit
-    bool walk(V3 ro, V3 rd, float t_max, bool any_hit, uint32_t* hid, float* ht, float* hu, float* hv, Counters* ctr) const {
+    // ---- the kernel's float pre-filter for triangles, operation for operation (pm_device.hpp tri_prefilter)
+    static V3 fcross(V3 a, V3 b) {
+        return V3(std::fmaf(a.y, b.z, -(a.z * b.y)), std::fmaf(a.z, b.x, -(a.x * b.z)), std::fmaf(a.x, b.y, -(a.y * b.x)));
+    }
+    static float fdot(V3 a, V3 b) { return std::fmaf(a.z, b.z, std::fmaf(a.y, b.y, a.x * b.x)); }
+    static float maxabs(V3 a) { float m = std::fabs(a.x); float y = std::fabs(a.y), z = std::fabs(a.z); if (!(y < m)) m = y; if (!(z < m)) m = z; return m; }
+    static int tri_prefilter(V3 ro, V3 rd, float R, float D, V3 v0, V3 v1, V3 v2, float tcull, float* t_hi) {
+        const float K = 7.62939453125e-06f;
+        V3 e1 = v1 - v0, e2 = v2 - v0, sv = ro - v0;
+        V3 pv = fcross(rd, e2);
+        float det = fdot(e1, pv), uu = fdot(sv, pv);
+        V3 qv = fcross(sv, e1);
+        float vv = fdot(rd, qv), tt = fdot(e2, qv);
+        float L = rmax(maxabs(e1), maxabs(e2)), S = maxabs(sv);
+        if (det < 0.0f) { det = -det; uu = -uu; vv = -vv; tt = -tt; }
+        float Sx = S + R + L;
+        float tb = K * D * L * Sx;
+        float ttau = K * L * L * Sx;
+        if (uu < -tb || vv < -tb || uu + vv > det + 2.0f * tb) return 0;
+        if (tt < -ttau) return 0;
+        if (tt > std::fmaf(tcull, det + tb, ttau)) return 0;
+        if (uu > tb && vv > tb && uu + vv < det - 2.0f * tb && det > 2.0f * tb && tt > ttau) {
+            float epsb = 8e-7f * (5.0f * R + D + 4.0f * (S + L));
+            float th = ((tt + ttau) / (det - tb)) * 1.00001f;
+            float tl = ((tt - ttau) / (det + tb)) * 0.99999f;
+            if (tl > epsb && th < tcull) { *t_hi = th; return 2; }
+        }
+        return 1;
+    }
+    static uint32_t nonzero_meta_mask(const WNode& nd) { uint32_t m = 0; for (int s = 0; s < 8; ++s) if (nd.meta[s]) m |= 1u << s; return m; }
+
+    // returns true if something was hit; closest-hit unless any_hit.  Mirrors pm_device.hpp traverse<>: pre-scaled slab test
+    // with folded margins, triangle pre-filter + queue of PM_CAND_MAX candidates tested exactly after the walk, culling by
+    // tcull, fallback walk with immediate exact tests when the exact tests do not confirm the culling.
+    bool walk(V3 ro, V3 rd, float ray_tmax, bool any_hit, uint32_t* hid, float* ht, float* hu, float* hv, Counters* ctr,
+              std::vector<uint8_t>* itrace = nullptr) const {
         const float widen = 1.0f + 2.0f * gamma_n(3);
+        const float MARGIN = 2.384185791015625e-07f;
+        const uint32_t CAND_MAX = 4;
         const float inv[3] = {1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
-        const uint32_t oct = (inv[0] < 0 ? 1u : 0u) | (inv[1] < 0 ? 2u : 0u) | (inv[2] < 0 ? 4u : 0u);
-        struct Group { uint32_t base, imask, pm; };
-        std::vector<Group> stack;
-        Group cur{0u, 1u, perm8(1u, oct)};
-        bool found = false;
-        *hid = 0xFFFFFFFFu; *ht = t_max; *hu = 0; *hv = 0;
+        const bool ng[3] = {inv[0] < 0, inv[1] < 0, inv[2] < 0};
+        const uint32_t oct = (ng[0] ? 1u : 0u) | (ng[1] ? 2u : 0u) | (ng[2] ? 4u : 0u);
+        const float R = maxabs(ro), D = maxabs(rd);
         const float o3[3] = {ro.x, ro.y, ro.z};
-        for (;;) {
-            if (cur.pm == 0) {
-                if (stack.empty()) break;
-                cur = stack.back(); stack.pop_back();
-                continue;
-            }
-            uint32_t k = 0; while (!(cur.pm & (1u << k))) ++k;
-            uint32_t slot = k ^ oct;
-            uint32_t nidx = cur.base + (uint32_t)__builtin_popcount(cur.imask & ((1u << slot) - 1u));
-            cur.pm &= ~(1u << k);
-            if (cur.pm) stack.push_back(cur);
-            const WNode& nd = nodes[nidx];
-            if (ctr) ctr->nodes_visited++;
-            float sc[3];
-            for (int a = 0; a < 3; ++a) sc[a] = u2f((uint32_t)nd.e[a] << 23);
-            uint32_t hits = 0;
-            for (int s = 0; s < 8; ++s) {
-                float t0 = 0.0f, t1 = t_max;
-                for (int a = 0; a < 3; ++a) {
-                    float lo = std::fmaf((float)nd.qlo[a][s], sc[a], nd.o[a]);
-                    float hi = std::fmaf((float)nd.qhi[a][s], sc[a], nd.o[a]);
-                    float x = (lo - o3[a]) * inv[a], y = (hi - o3[a]) * inv[a];
-                    t0 = rmax(t0, rmin(x, y));
-                    t1 = rmin(t1, rmax(x, y) * widen);
+        struct Group { uint32_t base, imask, pm; };
+        bool found = false;
+        bool exact_mode = false;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            float t_max = ray_tmax, tcull = ray_tmax;
+            bool sure = false;
+            std::vector<uint32_t> cand;
+            std::vector<Group> stack;
+            Group cur{0u, 1u, perm8(1u, oct)};
+            found = false;
+            *hid = 0xFFFFFFFFu; *ht = t_max; *hu = 0; *hv = 0;
+            for (;;) {
+                if (any_hit && (found || sure)) break;
+                if (cur.pm == 0) {
+                    if (stack.empty()) break;
+                    cur = stack.back(); stack.pop_back();
+                    if (itrace) itrace->push_back(255);
+                    continue;
                 }
-                bool valid = ((nd.imask >> s) & 1u) || nd.meta[s] != 0;
-                if (valid && !(t0 > t1)) hits |= 1u << s;
-            }
-            uint32_t lm = perm8(hits & ~(uint32_t)nd.imask, oct);
-            uint32_t type = nd.prim_base >> 30, pbase = nd.prim_base & 0x3FFFFFFFu;
-            uint32_t units = type == 2 ? 3 : (type == 1 ? 4 : 5);
-            for (uint32_t kl = 0; kl < 8; ++kl) {
-                if (!(lm & (1u << kl))) continue;
-                uint32_t ls = kl ^ oct;
-                uint32_t cnt = nd.meta[ls] >> 5, off = nd.meta[ls] & 31u;
-                for (uint32_t j = 0; j < cnt; ++j) {
-                    if (ctr) ctr->prims_tested++;
-                    uint32_t id; float t, u, v;
-                    if (test_prim(type, pbase + (off + j) * units, ro, rd, t_max, &id, &t, &u, &v)) {
-                        if (any_hit) return true;
-                        t_max = t; found = true; *hid = id; *ht = t; *hu = u; *hv = v;
+                if (itrace) itrace->push_back(0);
+                uint32_t k = 0; while (!(cur.pm & (1u << k))) ++k;
+                uint32_t slot = k ^ oct;
+                uint32_t nidx = cur.base + (uint32_t)__builtin_popcount(cur.imask & ((1u << slot) - 1u));
+                cur.pm &= ~(1u << k);
+                if (cur.pm) stack.push_back(cur);
+                const WNode& nd = nodes[nidx];
+                if (ctr) ctr->nodes_visited++;
+                float si[3], an[3], af[3], sf[3];
+                for (int a = 0; a < 3; ++a) {
+                    si[a] = u2f((uint32_t)nd.e[a] << 23) * inv[a];
+                    float ad = (nd.o[a] - o3[a]) * inv[a];
+                    float m = MARGIN * std::fmaf(256.0f, std::fabs(si[a]), std::fabs(ad));
+                    an[a] = ad - m; af[a] = (ad + m) * widen; sf[a] = si[a] * widen;
+                }
+                uint32_t hits = 0;
+                for (int s = 0; s < 8; ++s) {
+                    float tn[3], tf[3];
+                    for (int a = 0; a < 3; ++a) {
+                        float qn = (float)(ng[a] ? nd.qhi[a][s] : nd.qlo[a][s]), qf = (float)(ng[a] ? nd.qlo[a][s] : nd.qhi[a][s]);
+                        tn[a] = std::fmaf(qn, si[a], an[a]);
+                        tf[a] = std::fmaf(qf, sf[a], af[a]);
+                    }
+                    float n = rmax(rmax(tn[0], tn[1]), rmax(tn[2], 0.0f));
+                    float f = rmin(rmin(tf[0], tf[1]), rmin(tf[2], tcull));
+                    if (n <= f) hits |= 1u << s;
+                }
+                hits &= (uint32_t)nd.imask | nonzero_meta_mask(nd);
+                uint32_t lm = perm8(hits & ~(uint32_t)nd.imask, oct);
+                uint32_t type = nd.prim_base >> 30, pbase = nd.prim_base & 0x3FFFFFFFu;
+                uint32_t units = type == 2 ? 3 : (type == 1 ? 4 : 5);
+                for (uint32_t kl = 0; kl < 8 && !(any_hit && (found || sure)); ++kl) {
+                    if (!(lm & (1u << kl))) continue;
+                    uint32_t ls = kl ^ oct;
+                    uint32_t cnt = nd.meta[ls] >> 5, off = nd.meta[ls] & 31u;
+                    for (uint32_t j = 0; j < cnt && !(any_hit && (found || sure)); ++j) {
+                        if (ctr) ctr->prims_tested++;
+                        if (itrace && itrace->back() < 200) itrace->back()++;
+                        uint32_t unit = pbase + (off + j) * units;
+                        bool immediate = true;
+                        if (type == 2 && !exact_mode) {
+                            const float* f = reinterpret_cast<const float*>(prims + (size_t)unit * 16);
+                            float th;
+                            int cls = tri_prefilter(ro, rd, R, D, V3(f[0], f[1], f[2]), V3(f[3], f[4], f[5]), V3(f[6], f[7], f[8]), tcull, &th);
+                            if (cls == 0) immediate = false;
+                            else {
+                                if (cls == 2) { sure = true; if (!any_hit) tcull = th; }
+                                if (cand.size() < CAND_MAX) { cand.push_back(unit); immediate = false; }
+                            }
+                        }
+                        if (immediate) {
+                            if (ctr) ctr->exact_tests++;
+                            uint32_t id; float t, u, v;
+                            if (test_prim(type, unit, ro, rd, t_max, &id, &t, &u, &v)) {
+                                t_max = t; found = true; *hid = id; *ht = t; *hu = u; *hv = v;
+                                if (type != 2 || exact_mode) tcull = rmin(tcull, t);
+                            }
+                        }
                     }
                 }
+                cur = Group{nd.child_base, nd.imask, perm8(hits & nd.imask, oct)};
             }
-            cur = Group{nd.child_base, nd.imask, perm8(hits & nd.imask, oct)};
+            for (uint32_t unit : cand) {
+                if (any_hit && found) break;
+                if (ctr) ctr->exact_tests++;
+                uint32_t id; float t, u, v;
+                if (test_prim(2, unit, ro, rd, t_max, &id, &t, &u, &v)) { t_max = t; found = true; *hid = id; *ht = t; *hu = u; *hv = v; }
+            }
+            bool confirmed = !sure || (found && (any_hit || *ht <= tcull));
+            if (confirmed || exact_mode) break;
+            exact_mode = true;
+            if (ctr) ctr->fallback_walks++;
         }
         return found;
     }

@@ -35,7 +35,7 @@ class PmAccelInfo(C.Structure):
 
 class PmCounters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64),
-                ("stack_overflows", C.c_uint64)]
+                ("stack_overflows", C.c_uint64), ("exact_tests", C.c_uint64), ("fallback_walks", C.c_uint64)]
 
 
 class PmSpectrum(C.Structure):

@@ -131,7 +131,7 @@ class GpuAggregate:
         c = PmCounters()
         self._check(self._lib.pm_get_counters(self._h, C.byref(c)))
         return {"rays": c.rays, "nodes_visited": c.nodes_visited, "prims_tested": c.prims_tested,
-                "stack_overflows": c.stack_overflows}
+                "stack_overflows": c.stack_overflows, "exact_tests": c.exact_tests, "fallback_walks": c.fallback_walks}
 
     def last_kernel_ms(self):
         ms = C.c_float()

@@ -4,43 +4,41 @@
 #include "pm_device.hpp"
 
 // ------------------------------------------------------------------------------------------ kernels
-// XCD-aware block remap: hardware deals consecutive workgroups round-robin over the 8 XCDs (each with
-// a private 4 MiB L2), so block b and b+8 share an L2.  Give every XCD one contiguous span of the ray
-// array, so rays that are neighbours in the (tile-ordered) input walk the same BVH region in one L2.
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
-    const uint32_t q = nb >> 3, r = nb & 7u, x = b & 7u;
-    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (b >> 3);
-}
-
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const PmWideNode* __restrict__ nodes,
                                                             const uint4* __restrict__ prims,
-                                                            const PmRay* __restrict__ rays, uint64_t n,
+                                                            const PmRay* __restrict__ rays, uint32_t n,
                                                             PmHit* __restrict__ hits, uint8_t* __restrict__ occ,
+                                                            uint32_t* __restrict__ work,
                                                             unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TRACE_BLOCK];
-    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
-    const uint64_t i = (uint64_t)blk * TRACE_BLOCK + threadIdx.x;
-    pmd::TravCounters tc = {0u, 0u, 0u};
-    if (i < n) {
+    __shared__ uint32_t cand[PM_CAND_MAX * TRACE_BLOCK];
+    pmd::TravCounters tc = {0u, 0u, 0u, 0u, 0u};
+    auto fetch = [&](uint32_t i, pmd::Ray* ray) -> bool {
         const float4* rp = reinterpret_cast<const float4*>(rays + i);
         const float4 a = rp[0], b = rp[1];
-        pmd::Ray ray;
-        ray.o = pmd::mk3(a.x, a.y, a.z); ray.tmax = a.w; ray.d = pmd::mk3(b.x, b.y, b.z);
-        pmd::HitRec h;
-        const bool f = pmd::traverse<ANY, COUNT>(nodes, prims, ray, &h, stack + threadIdx.x, TRACE_BLOCK, &tc);
-        if (ANY) occ[i] = f ? 1 : 0;
+        ray->o = pmd::mk3(a.x, a.y, a.z); ray->tmax = a.w; ray->d = pmd::mk3(b.x, b.y, b.z);
+        return true;
+    };
+    auto commit = [&](uint32_t i, bool found, const pmd::HitRec& h) {
+        if (ANY) occ[i] = found ? 1 : 0;
         else {
             float4 o;
             o.x = __uint_as_float(h.prim_id); o.y = h.t; o.z = h.u; o.w = h.v;
             *reinterpret_cast<float4*>(hits + i) = o;
         }
-    }
+    };
+    pmd::trace_persistent<ANY, COUNT>(nodes, prims, n, work, stack + threadIdx.x, cand + threadIdx.x, TRACE_BLOCK, &tc, fetch, commit);
     if (COUNT) {
         // wave-level reduction, one atomic per wave per counter
-        unsigned long long nn = tc.nodes, pp = tc.prims;
-        for (int off = 32; off > 0; off >>= 1) { nn += __shfl_down(nn, off); pp += __shfl_down(pp, off); }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&counters[1], nn); atomicAdd(&counters[2], pp); }
+        unsigned long long nn = tc.nodes, pp = tc.prims, ee = tc.exact, ff = tc.fallback;
+        for (int off = 32; off > 0; off >>= 1) {
+            nn += __shfl_down(nn, off); pp += __shfl_down(pp, off); ee += __shfl_down(ee, off); ff += __shfl_down(ff, off);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&counters[1], nn); atomicAdd(&counters[2], pp); atomicAdd(&counters[6], ee);
+            if (ff) atomicAdd(&counters[7], ff);
+        }
     }
     if (tc.overflow) atomicAdd(&counters[3], 1ull);
 }
@@ -62,7 +60,9 @@ extern "C" int pm_create(int device_id, pm_ctx** out) {
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(&c->d_work, PM_WORK_SLOTS * sizeof(uint32_t)) != hipSuccess ||
+        hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) {
         delete c;
         return PM_ERR_HIP;
     }
@@ -78,6 +78,7 @@ extern "C" void pm_destroy(pm_ctx* c) {
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     if (c->d_prims) (void)hipFree(c->d_prims);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_work) (void)hipFree(c->d_work);
     if (c->d_stage_in) (void)hipFree(c->d_stage_in);
     if (c->d_stage_out) (void)hipFree(c->d_stage_out);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -225,7 +226,6 @@ static int trace_impl(pm_ctx* c, const PmRay* rays, uint64_t n, void* out, size_
     if (!c->accel_valid) return fail(c, PM_ERR_NO_ACCEL, "trace: pm_build_accel has not been called");
     if (n == 0) { c->last_ms = 0.f; return PM_OK; }
     if (!rays || !out) return fail(c, PM_ERR_INVALID, "trace: null rays/out");
-    if (n > (uint64_t)TRACE_BLOCK * 0x7FFFFFFFull) return fail(c, PM_ERR_INVALID, "trace: too many rays in one call");
     HIPCHK(c, hipSetDevice(c->device));
     const bool in_dev = is_device_ptr(rays), out_dev = is_device_ptr(out);
     const PmRay* d_rays = rays;
@@ -243,14 +243,25 @@ static int trace_impl(pm_ctx* c, const PmRay* rays, uint64_t n, void* out, size_
     }
     unsigned long long before[4];
     HIPCHK(c, hipMemcpyAsync(before, c->d_counters, sizeof(before), hipMemcpyDeviceToHost, c->stream));
-    const uint32_t grid = (uint32_t)((n + TRACE_BLOCK - 1) / TRACE_BLOCK);
+    // persistent waves pull ray indices from a work counter; one launch covers at most 2^30 rays
+    const uint64_t chunk = 1ull << 30;
+    const uint64_t n_chunks = (n + chunk - 1) / chunk;
+    if (n_chunks > PM_WORK_SLOTS) return fail(c, PM_ERR_INVALID, "trace: too many rays in one call");
+    HIPCHK(c, hipMemsetAsync(c->d_work, 0, PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (c->counting)
-        hipLaunchKernelGGL((trace_kernel<ANY, true>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_nodes, c->d_prims,
-                           d_rays, n, ANY ? nullptr : (PmHit*)d_out, ANY ? (uint8_t*)d_out : nullptr, c->d_counters);
-    else
-        hipLaunchKernelGGL((trace_kernel<ANY, false>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_nodes, c->d_prims,
-                           d_rays, n, ANY ? nullptr : (PmHit*)d_out, ANY ? (uint8_t*)d_out : nullptr, c->d_counters);
+    for (uint64_t k = 0; k < n_chunks; ++k) {
+        const uint64_t b = k * chunk;
+        const uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - b);
+        const uint32_t grid = std::min<uint32_t>((m + TRACE_BLOCK - 1) / TRACE_BLOCK, (uint32_t)c->n_cu * PM_BLOCKS_PER_CU);
+        PmHit* oh = ANY ? nullptr : (PmHit*)d_out + b;
+        uint8_t* oo = ANY ? (uint8_t*)d_out + b : nullptr;
+        if (c->counting)
+            hipLaunchKernelGGL((trace_kernel<ANY, true>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_nodes, c->d_prims,
+                               d_rays + b, m, oh, oo, c->d_work + k, c->d_counters);
+        else
+            hipLaunchKernelGGL((trace_kernel<ANY, false>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_nodes, c->d_prims,
+                               d_rays + b, m, oh, oo, c->d_work + k, c->d_counters);
+    }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     if (!out_dev) HIPCHK(c, hipMemcpyAsync(out, d_out, n * out_elem, hipMemcpyDeviceToHost, c->stream));
@@ -281,9 +292,10 @@ extern "C" int pm_reset_counters(pm_ctx* c) {
 extern "C" int pm_get_counters(pm_ctx* c, PmCounters* out) {
     if (!c || !out || c->device < 0) return PM_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    unsigned long long v[4];
+    unsigned long long v[8];
     HIPCHK(c, hipMemcpy(v, c->d_counters, sizeof(v), hipMemcpyDeviceToHost));
-    out->rays = c->rays_counted; out->nodes_visited = v[1]; out->prims_tested = v[2]; out->stack_overflows = v[3];
+    out->rays = c->rays_counted; out->nodes_visited = v[1] + v[4]; out->prims_tested = v[2] + v[5]; out->stack_overflows = v[3];
+    out->exact_tests = v[6]; out->fallback_walks = v[7];
     return PM_OK;
 }
 extern "C" int pm_last_kernel_ms(pm_ctx* c, float* ms) { if (!c || !ms) return PM_ERR_INVALID; *ms = c->last_ms; return PM_OK; }

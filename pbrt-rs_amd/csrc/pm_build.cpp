@@ -159,8 +159,10 @@ static void quantise_node(PmWideNode& wn, const Box& nb, const Box* cb, const bo
             int qh = (int)std::ceil((cb[c].hi[k] - wn.o[k]) / s);
             ql = std::max(0, std::min(255, ql));
             qh = std::max(0, std::min(255, qh));
-            while (ql > 0 && std::fmaf((float)ql, s, wn.o[k]) > cb[c].lo[k]) --ql;
-            while (qh < 255 && std::fmaf((float)qh, s, wn.o[k]) < cb[c].hi[k]) ++qh;
+            // conservative against the EXACT plane o + q*s (evaluated in double: exact), which implies it for the
+            // f32-rounded decode too; the kernel's pre-scaled slab test relies on the exact form
+            while (ql > 0 && (double)ql * (double)s + (double)wn.o[k] > (double)cb[c].lo[k]) --ql;
+            while (qh < 255 && (double)qh * (double)s + (double)wn.o[k] < (double)cb[c].hi[k]) ++qh;
             wn.qlo[k][c] = (uint8_t)ql;
             wn.qhi[k][c] = (uint8_t)qh;
         }

@@ -14,6 +14,8 @@
 struct RenderState;   // pm_render.hip
 
 #define TRACE_BLOCK 128
+#define PM_WORK_SLOTS 64
+#define PM_BLOCKS_PER_CU 8      // persistent traversal grids: 8 blocks x 2 waves per CU = 4 waves per SIMD
 
 struct pm_ctx {
     int device = 0;
@@ -26,7 +28,9 @@ struct pm_ctx {
     int split_method = PM_SPLIT_SAH;
     PmWideNode* d_nodes = nullptr;
     uint4* d_prims = nullptr;
-    unsigned long long* d_counters = nullptr;   // rays, nodes, prims, overflow
+    unsigned long long* d_counters = nullptr;   // [1] nodes [2] prims [3] overflow [4] shadow nodes [5] shadow prims [6] exact [7] fallback
+    uint32_t* d_work = nullptr;                 // PM_WORK_SLOTS work-item counters of the persistent traversal kernels
+    int n_cu = 256;
     bool counting = false;
     uint64_t rays_counted = 0;
     float last_ms = 0.0f;

@@ -214,138 +214,312 @@ PMD uint32_t perm8(uint32_t m, uint32_t oct) {   // bit k of result = bit (k ^ o
     return m;
 }
 PMD float ubyte(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }
+// bit k of the result = (byte k of w != 0), k = 0..3
+PMD uint32_t nonzero_bytes4(uint32_t w) {
+    const uint32_t t = ((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w;          // bit 7 of each byte = byte != 0
+    return ((((t >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+}
 
-struct TravCounters { uint32_t nodes, prims, overflow; };
+struct TravCounters { uint32_t nodes, prims, exact, overflow, fallback; };
 
-// One ray through the wide BVH.  ANY: stop at the first accepted primitive (intersect_p);
-// otherwise shrink tmax on every accepted primitive (intersect).  `lds` is this lane's column of
-// the per-block LDS stack: entry e of lane l lives at lds[e * stride + l].
-template <bool ANY, bool COUNT>
-PMD bool traverse(const PmWideNode* __restrict__ nodes, const uint4* __restrict__ prims, Ray ray, HitRec* hit,
-                  uint2* lds, int stride, TravCounters* ctr) {
+// The reference's patch test specialised to the degenerate patch (v0, v1, v2, v2) that a triangle is: the quadratic
+// coefficient a = dot(cross(p10-p00, p01-p11), d) is (+-)0 for p11 == p01, so there is one root u = -c/b.  Same
+// operations in the same order as intersect_patch => same bits.
+PMD bool intersect_tri_exact(f3 ro, f3 rd, float t_max, f3 p00, f3 p10, f3 p01, float* to, float* uo, float* vo) {
+    float c = dot3(cross3(p00 - ro, rd), p01 - p00);
+    float b = dot3(cross3(p10 - ro, rd), p01 - p10) - c;
+    if (b == 0.0f) return false;
+    const float u1 = -c / b;
+    float eps = gamma_n(10) * (maxc3(abs3(ro)) + maxc3(abs3(rd)) + maxc3(abs3(p00)) + maxc3(abs3(p10)) +
+                               maxc3(abs3(p01)) + maxc3(abs3(p01)));
+    float t = t_max, u = 0.0f, v = 0.0f;
+    if (u1 >= 0.0f && u1 <= 1.0f) {
+        float vn, tn, p2;
+        patch_root(ro, rd, p00, p10, p01, p01, u1, &vn, &tn, &p2);
+        if (tn > p2 * eps && (vn >= 0.0f && vn <= p2)) { u = u1; v = vn / p2; t = tn / p2; }
+    }
+    if (t < t_max) { *to = t; *uo = u; *vo = v; return true; }
+    return false;
+}
+
+// ---- float pre-filter for triangles (Moeller-Trumbore with forward error margins; fused multiply-adds are fine here:
+// only the classification matters, and the CPU walker in oracle/wide_walk.h repeats the same operations).
+//   0  the exact test cannot accept this triangle with t <= tcull     -> skipped
+//   1  undecided                                                      -> exact test later
+//   2  the exact test accepts it, with t <= *t_hi                     -> exact test later, *t_hi may cull now
+#define PM_PRE_K 7.62939453125e-06f      /* 128 * 2^-24 */
+PMD f3 fcross(f3 a, f3 b) {
+    return mk3(__fmaf_rn(a.y, b.z, -(a.z * b.y)), __fmaf_rn(a.z, b.x, -(a.x * b.z)), __fmaf_rn(a.x, b.y, -(a.y * b.x)));
+}
+PMD float fdot(f3 a, f3 b) { return __fmaf_rn(a.z, b.z, __fmaf_rn(a.y, b.y, a.x * b.x)); }
+PMD int tri_prefilter(f3 ro, f3 rd, float R, float D, f3 v0, f3 v1, f3 v2, float tcull, float* t_hi) {
+    const f3 e1 = v1 - v0, e2 = v2 - v0, sv = ro - v0;
+    const f3 pv = fcross(rd, e2);
+    float det = fdot(e1, pv), uu = fdot(sv, pv);
+    const f3 qv = fcross(sv, e1);
+    float vv = fdot(rd, qv), tt = fdot(e2, qv);
+    const float L = fmaxf(maxc3(abs3(e1)), maxc3(abs3(e2))), S = maxc3(abs3(sv));
+    if (det < 0.0f) { det = -det; uu = -uu; vv = -vv; tt = -tt; }
+    // error bounds.  The pre-filter itself works on differences (errors relative to L, S), but the exact test it must agree
+    // with rounds absolute coordinates (errors relative to |ro| + |p| <= 2R + S + L), so the bounds carry Sx = S + R + L.
+    const float Sx = S + R + L;
+    const float tb = PM_PRE_K * D * L * Sx;            // bound for det, uu, vv
+    const float ttau = PM_PRE_K * L * L * Sx;          // bound for tt
+    if (uu < -tb || vv < -tb || uu + vv > det + 2.0f * tb) return 0;
+    if (tt < -ttau) return 0;
+    if (tt > __fmaf_rn(tcull, det + tb, ttau)) return 0;
+    // certain hit: inside by more than the error bounds; t bracketed by [ (tt - ttau)/(det + tb), (tt + ttau)/(det - tb) ]
+    if (uu > tb && vv > tb && uu + vv < det - 2.0f * tb && det > 2.0f * tb && tt > ttau) {
+        const float epsb = 8e-7f * (5.0f * R + D + 4.0f * (S + L));     // >= the exact test's gamma(10) * sum of max-abs
+        const float th = ((tt + ttau) / (det - tb)) * 1.00001f;
+        const float tl = ((tt - ttau) / (det + tb)) * 0.99999f;
+        if (tl > epsb && th < tcull) { *t_hi = th; return 2; }
+    }
+    return 1;
+}
+
+#define PM_CAND_MAX 4
+#define PM_NODE_MARGIN 2.384185791015625e-07f   /* 4 * 2^-24: rounding of the pre-scaled slab evaluation */
+#define PM_REFILL 24                            /* a wave refills its idle lanes when at least this many are idle */
+#define PM_WALK_GUARD (1u << 22)                /* per-ray bound on node steps (a corrupt buffer cannot hang a wave) */
+
+// Rays through the wide BVH, persistent waves.  ANY: intersect_p (is anything hit before ray.tmax); otherwise closest hit.
+//
+// Every wave pulls work items from one global counter: when PM_REFILL or more of its lanes are idle, the lanes whose walk
+// has ended run their exact tests together and commit, then all idle lanes fetch the next items (one atomic per refill).
+// This keeps the lanes of a wave busy although walks differ a lot in length (a wave otherwise runs as long as its
+// longest walk: ~3x the mean node steps on the C3 primary rays, oracle/oracle_api.cpp wave model).
+//
+// Triangles go through tri_prefilter; survivors are queued (PM_CAND_MAX per ray, in LDS) and get the exact
+// (reference-arithmetic) test when the walk has ended instead of diverging inside it.  Culling uses `tcull`, an upper
+// bound of the final closest t that only certain hits lower; exact results never feed back into the walk, so the walk of a
+// ray does not depend on its wave (the counters are deterministic).  If the exact tests do not confirm what culling
+// assumed (it would take an error-analysis failure; counted in fallback), the ray is walked again with immediate exact
+// tests, so results are exact regardless.
+//
+//   fetch(i, &ray) -> bool   load work item i (false: nothing to trace for it)
+//   commit(i, found, hit)    store the result of work item i
+// `lds` is this lane's column of the per-block LDS stack (entry e at lds[e * stride]); `cand` this lane's column of the
+// candidate queue.
+template <bool ANY, bool COUNT, class FetchFn, class CommitFn>
+PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __restrict__ prims, uint32_t n_items,
+                          uint32_t* __restrict__ work_counter, uint2* lds, uint32_t* cand, int stride, TravCounters* ctr,
+                          FetchFn fetch, CommitFn commit) {
     const float widen = 1.0f + 2.0f * gamma_n(3);
-    const f3 inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-    const uint32_t oct = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
-    float tmax = ray.tmax;
-    bool found = false;
-    hit->prim_id = 0xFFFFFFFFu; hit->t = tmax; hit->u = 0.0f; hit->v = 0.0f;
-
-    uint2 spill[PM_SPILL_STACK];
+    const uint32_t lane = threadIdx.x & 63u;
+    bool active = false;       // this lane is walking a ray
+    bool finished = false;     // its walk has ended; exact tests + commit pending
+    bool more = true;          // wave-uniform: the pool may still hold items
+    uint32_t item = 0, steps = 0;
+    Ray ray; ray.o = mk3(0.f, 0.f, 0.f); ray.d = mk3(0.f, 0.f, 1.f); ray.tmax = 0.f;
+    f3 inv = mk3(0.f, 0.f, 0.f);
+    bool ngx = false, ngy = false, ngz = false;
+    uint32_t oct = 0;
+    float R = 0.f, D = 0.f, tmax = 0.f, tcull = 0.f;
+    bool sure = false, found = false, exact_mode = false;
+    uint32_t qn = 0;
     int sp = 0;
-    // current group: x = child_base, y = (imask << 8) | permuted hit mask.  Start with a pseudo group
-    // holding only the root (index 0).
-    uint2 cur = make_uint2(0u, (1u << 8) | perm8(1u, oct));
+    uint2 cur = make_uint2(0u, 0u);
+    HitRec hit; hit.prim_id = 0xFFFFFFFFu; hit.t = 0.f; hit.u = 0.f; hit.v = 0.f;
+    uint2 spill[PM_SPILL_STACK];
 
-    // every lane leaves this loop: the tree is finite, and `guard` bounds the walk even if a buffer is corrupt
-    for (uint32_t guard = 0; guard < (1u << 22); ++guard) {
-        if (ANY && found) break;
-        uint32_t pm = cur.y & 0xFFu;
-        if (pm == 0u) {
-            if (sp == 0) break;
-            --sp;
-            cur = sp < PM_LDS_STACK ? lds[sp * stride] : spill[sp - PM_LDS_STACK];
-            continue;
-        }
-        const uint32_t k = __ffs(pm) - 1u;
-        const uint32_t slot = k ^ oct;
-        const uint32_t imask_g = cur.y >> 8;
-        const uint32_t nidx = cur.x + __popc(imask_g & ((1u << slot) - 1u));
-        cur.y &= ~(1u << k);
-        if (cur.y & 0xFFu) {
-            if (sp < PM_LDS_STACK) lds[sp * stride] = cur;
-            else if (sp < PM_LDS_STACK + PM_SPILL_STACK) spill[sp - PM_LDS_STACK] = cur;
-            else { ctr->overflow = 1; --sp; }
-            ++sp;
-        }
-        // ---- fetch the 80-byte node (5 x 16 B)
-        const uint4* np = reinterpret_cast<const uint4*>(nodes + nidx);
-        const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-        if (COUNT) ctr->nodes++;
-        const float ox = __uint_as_float(n0.x), oy = __uint_as_float(n0.y), oz = __uint_as_float(n0.z);
-        const float sx = __uint_as_float((n0.w & 0xFFu) << 23);
-        const float sy = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23);
-        const float sz = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23);
-        const uint32_t imask = n0.w >> 24;
-        const uint32_t metaw[2] = {n1.z, n1.w};
-        const uint32_t qlx[2] = {n2.x, n2.y}, qly[2] = {n2.z, n2.w}, qlz[2] = {n3.x, n3.y};
-        const uint32_t qhx[2] = {n3.z, n3.w}, qhy[2] = {n4.x, n4.y}, qhz[2] = {n4.z, n4.w};
-        uint32_t hits = 0;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int w = s >> 2, kk = s & 3;
-            const float lx = __fmaf_rn(ubyte(qlx[w], kk), sx, ox), hx = __fmaf_rn(ubyte(qhx[w], kk), sx, ox);
-            const float ly = __fmaf_rn(ubyte(qly[w], kk), sy, oy), hy = __fmaf_rn(ubyte(qhy[w], kk), sy, oy);
-            const float lz = __fmaf_rn(ubyte(qlz[w], kk), sz, oz), hz = __fmaf_rn(ubyte(qhz[w], kk), sz, oz);
-            float a = (lx - ray.o.x) * inv.x, b = (hx - ray.o.x) * inv.x;
-            float t0 = fmaxf(0.0f, fminf(a, b));
-            float t1 = fminf(tmax, fmaxf(a, b) * widen);
-            a = (ly - ray.o.y) * inv.y; b = (hy - ray.o.y) * inv.y;
-            t0 = fmaxf(t0, fminf(a, b));
-            t1 = fminf(t1, fmaxf(a, b) * widen);
-            a = (lz - ray.o.z) * inv.z; b = (hz - ray.o.z) * inv.z;
-            t0 = fmaxf(t0, fminf(a, b));
-            t1 = fminf(t1, fmaxf(a, b) * widen);
-            const bool valid = ((imask >> s) & 1u) || (((metaw[w] >> (8 * kk)) & 0xFFu) != 0u);
-            if (valid && !(t0 > t1)) hits |= 1u << s;
-        }
-        // ---- leaves of this node, front to back by octant order
-        uint32_t lm = perm8(hits & ~imask, oct);
-        const uint32_t ptype = n1.y >> 30;
-        const uint32_t pbase = n1.y & 0x3FFFFFFFu;
-        while (lm && !(ANY && found)) {
-            const uint32_t kl = __ffs(lm) - 1u;
-            lm &= lm - 1u;
-            const uint32_t ls = kl ^ oct;
-            const uint32_t meta = (metaw[ls >> 2] >> (8 * (ls & 3))) & 0xFFu;
-            const uint32_t cnt = meta >> 5, off = meta & 31u;
-            for (uint32_t j = 0; j < cnt && !(ANY && found); ++j) {
-                if (COUNT) ctr->prims++;
-                if (ptype == PM_PRIM_TRI) {
-                    const uint4* r = prims + pbase + (off + j) * PM_UNITS_TRI;
+    auto start_walk = [&]() {
+        tmax = ray.tmax; tcull = ray.tmax; sure = false; found = false; qn = 0; sp = 0; steps = 0;
+        hit.prim_id = 0xFFFFFFFFu; hit.t = ray.tmax; hit.u = 0.0f; hit.v = 0.0f;
+        cur = make_uint2(0u, (1u << 8) | perm8(1u, oct));     // pseudo group holding only the root
+        active = true;
+    };
+
+    // Work items are reserved from the global counter in chunks (one atomic per chunk, not per refill) sized so that every
+    // wave of the grid gets several chunks: [wnext, wend) is this wave's current reservation (wave-uniform).
+    uint32_t chunk = n_items / (gridDim.x * (blockDim.x >> 6) * 4u);
+    chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : (chunk & ~63u));
+    uint32_t wnext = 0, wend = 0;
+
+    for (;;) {
+        const uint32_t n_idle = (uint32_t)__popcll(__ballot(!active));
+        if (n_idle == 64u || ((more || wnext < wend) && n_idle >= PM_REFILL)) {
+            // ---- lanes whose walk has ended: exact tests of the queued triangles, in the order they were met
+            if (finished) {
+                for (uint32_t qi = 0; qi < PM_CAND_MAX; ++qi) {
+                    if (qi >= qn || (ANY && found)) continue;
+                    const uint4* r = prims + cand[qi * stride];
                     const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
-                    f3 v0 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
-                    f3 v1 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
-                    f3 v2 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
+                    const f3 v0 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
+                    const f3 v1 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
+                    const f3 v2 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
+                    if (COUNT) ctr->exact++;
                     float t, u, v;
-                    if (intersect_patch(ray.o, ray.d, tmax, v0, v1, v2, v2, &t, &u, &v)) {
-                        tmax = t; found = true; hit->prim_id = r2.y; hit->t = t; hit->u = u; hit->v = v;
-                    }
-                } else if (ptype == PM_PRIM_PATCH) {
-                    const uint4* r = prims + pbase + (off + j) * PM_UNITS_PATCH;
-                    const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-                    f3 p00 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
-                    f3 p10 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
-                    f3 p01 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
-                    f3 p11 = mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
-                    float t, u, v;
-                    if (intersect_patch(ray.o, ray.d, tmax, p00, p10, p01, p11, &t, &u, &v)) {
-                        tmax = t; found = true; hit->prim_id = r3.x; hit->t = t; hit->u = u; hit->v = v;
-                    }
-                } else {
-                    const uint4* r = prims + pbase + (off + j) * PM_UNITS_SPHERE;
-                    float m[12];
-                    const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
-                    m[0] = __uint_as_float(r0.x); m[1] = __uint_as_float(r0.y); m[2] = __uint_as_float(r0.z); m[3] = __uint_as_float(r0.w);
-                    m[4] = __uint_as_float(r1.x); m[5] = __uint_as_float(r1.y); m[6] = __uint_as_float(r1.z); m[7] = __uint_as_float(r1.w);
-                    m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
-                    const float radius = __uint_as_float(r3.x), zmin = __uint_as_float(r3.y), zmax = __uint_as_float(r3.z),
-                                phimax = __uint_as_float(r3.w);
-                    SphereHit sh;
-                    if (intersect_sphere(ray.o, ray.d, tmax, m, radius, zmin, zmax, phimax, &sh)) {
-                        tmax = sh.t; found = true; hit->prim_id = r4.x; hit->t = sh.t;
-                        // (u,v) of sphere.rs:382-385
-                        const float th0 = acosf(fminf(fmaxf(zmin / radius, -1.0f), 1.0f));
-                        const float th1 = acosf(fminf(fmaxf(zmax / radius, -1.0f), 1.0f));
-                        const float th = acosf(fminf(fmaxf(sh.p_obj.z / radius, -1.0f), 1.0f));
-                        hit->u = sh.phi / phimax; hit->v = (th - th0) / (th1 - th0);
+                    if (intersect_tri_exact(ray.o, ray.d, tmax, v0, v1, v2, &t, &u, &v)) {
+                        tmax = t; found = true; hit.prim_id = r2.y; hit.t = t; hit.u = u; hit.v = v;
                     }
                 }
+                finished = false;
+                // did the exact tests confirm what culling assumed?
+                const bool confirmed = !sure || (found && (ANY || hit.t <= tcull));
+                if (confirmed || exact_mode) commit(item, found, hit);
+                else { exact_mode = true; if (COUNT) ctr->fallback++; start_walk(); }
+            }
+            // ---- idle lanes fetch the next items
+            if (wnext >= wend && more) {
+                uint32_t base = 0;
+                if (lane == 0u) base = atomicAdd(work_counter, chunk);
+                base = __shfl(base, 0);
+                if (base < n_items) { wnext = base; wend = base + chunk < n_items ? base + chunk : n_items; }
+                else more = false;
+            }
+            if (wnext < wend) {
+                const unsigned long long want = __ballot(!active);
+                if (!active) {
+                    const uint32_t idx = wnext + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+                    if (idx < wend && fetch(idx, &ray)) {
+                        item = idx;
+                        inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+                        ngx = inv.x < 0.0f; ngy = inv.y < 0.0f; ngz = inv.z < 0.0f;
+                        oct = (ngx ? 1u : 0u) | (ngy ? 2u : 0u) | (ngz ? 4u : 0u);
+                        R = maxc3(abs3(ray.o)); D = maxc3(abs3(ray.d));
+                        exact_mode = false;
+                        start_walk();
+                    }
+                }
+                const uint32_t nw = (uint32_t)__popcll(want);
+                wnext = wnext + nw < wend ? wnext + nw : wend;
+            }
+            if (!__any(active) && !more && wnext >= wend) break;
+        }
+        if (active) {
+            // ---- one node step (the pop of an exhausted group is merged into it)
+            bool ended = (ANY && (found || sure)) || ++steps > PM_WALK_GUARD;
+            uint32_t pm = cur.y & 0xFFu;
+            if (!ended && pm == 0u) {
+                if (sp == 0) ended = true;
+                else {
+                    --sp;
+                    cur = sp < PM_LDS_STACK ? lds[sp * stride] : spill[sp - PM_LDS_STACK];
+                    pm = cur.y & 0xFFu;
+                }
+            }
+            if (ended) { active = false; finished = true; }
+            else {
+                const uint32_t k = __ffs(pm) - 1u;
+                const uint32_t slot = k ^ oct;
+                const uint32_t imask_g = cur.y >> 8;
+                const uint32_t nidx = cur.x + __popc(imask_g & ((1u << slot) - 1u));
+                cur.y &= ~(1u << k);
+                if (cur.y & 0xFFu) {
+                    if (sp < PM_LDS_STACK) lds[sp * stride] = cur;
+                    else if (sp < PM_LDS_STACK + PM_SPILL_STACK) spill[sp - PM_LDS_STACK] = cur;
+                    else { ctr->overflow = 1; --sp; }
+                    ++sp;
+                }
+                // ---- fetch the 80-byte node (5 x 16 B)
+                const uint4* np = reinterpret_cast<const uint4*>(nodes + nidx);
+                const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+                if (COUNT) ctr->nodes++;
+                const uint32_t imask = n0.w >> 24;
+                const uint32_t vmask = imask | nonzero_bytes4(n1.z) | (nonzero_bytes4(n1.w) << 4);
+                // ---- pre-scaled slab test: t = q * (scale/d) + (origin - o)/d, margins folded into the addends
+                const float sxi = __uint_as_float((n0.w & 0xFFu) << 23) * inv.x;
+                const float syi = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23) * inv.y;
+                const float szi = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23) * inv.z;
+                const float ax = (__uint_as_float(n0.x) - ray.o.x) * inv.x;
+                const float ay = (__uint_as_float(n0.y) - ray.o.y) * inv.y;
+                const float az = (__uint_as_float(n0.z) - ray.o.z) * inv.z;
+                const float mx = PM_NODE_MARGIN * __fmaf_rn(256.0f, fabsf(sxi), fabsf(ax));
+                const float my = PM_NODE_MARGIN * __fmaf_rn(256.0f, fabsf(syi), fabsf(ay));
+                const float mz = PM_NODE_MARGIN * __fmaf_rn(256.0f, fabsf(szi), fabsf(az));
+                const float anx = ax - mx, any_ = ay - my, anz = az - mz;
+                const float afx = (ax + mx) * widen, afy = (ay + my) * widen, afz = (az + mz) * widen;
+                const float sxf = sxi * widen, syf = syi * widen, szf = szi * widen;
+                // near / far plane bytes by direction sign: lo words n2.x n2.y | n2.z n2.w | n3.x n3.y, hi words n3.z n3.w | n4.x n4.y | n4.z n4.w
+                const uint32_t qnx[2] = {ngx ? n3.z : n2.x, ngx ? n3.w : n2.y}, qfx[2] = {ngx ? n2.x : n3.z, ngx ? n2.y : n3.w};
+                const uint32_t qny[2] = {ngy ? n4.x : n2.z, ngy ? n4.y : n2.w}, qfy[2] = {ngy ? n2.z : n4.x, ngy ? n2.w : n4.y};
+                const uint32_t qnz[2] = {ngz ? n4.z : n3.x, ngz ? n4.w : n3.y}, qfz[2] = {ngz ? n3.x : n4.z, ngz ? n3.y : n4.w};
+                uint32_t hits = 0;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const int w = s >> 2, kk = s & 3;
+                    const float tn = fmaxf(fmaxf(__fmaf_rn(ubyte(qnx[w], kk), sxi, anx), __fmaf_rn(ubyte(qny[w], kk), syi, any_)),
+                                           fmaxf(__fmaf_rn(ubyte(qnz[w], kk), szi, anz), 0.0f));
+                    const float tf = fminf(fminf(__fmaf_rn(ubyte(qfx[w], kk), sxf, afx), __fmaf_rn(ubyte(qfy[w], kk), syf, afy)),
+                                           fminf(__fmaf_rn(ubyte(qfz[w], kk), szf, afz), tcull));
+                    if (tn <= tf) hits |= 1u << s;
+                }
+                hits &= vmask;
+                // ---- leaves of this node, front to back by octant order
+                uint32_t lm = perm8(hits & ~imask, oct);
+                const uint32_t ptype = n1.y >> 30;
+                const uint32_t pbase = n1.y & 0x3FFFFFFFu;
+                const uint32_t metaw[2] = {n1.z, n1.w};
+                while (lm && !(ANY && (found || sure))) {
+                    const uint32_t kl = __ffs(lm) - 1u;
+                    lm &= lm - 1u;
+                    const uint32_t ls = kl ^ oct;
+                    const uint32_t meta = (metaw[ls >> 2] >> (8 * (ls & 3))) & 0xFFu;
+                    const uint32_t cnt = meta >> 5, off = meta & 31u;
+                    for (uint32_t j = 0; j < cnt && !(ANY && (found || sure)); ++j) {
+                        if (COUNT) ctr->prims++;
+                        if (ptype == PM_PRIM_SPHERE) {
+                            const uint4* r = prims + pbase + (off + j) * PM_UNITS_SPHERE;
+                            float m[12];
+                            const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+                            m[0] = __uint_as_float(r0.x); m[1] = __uint_as_float(r0.y); m[2] = __uint_as_float(r0.z); m[3] = __uint_as_float(r0.w);
+                            m[4] = __uint_as_float(r1.x); m[5] = __uint_as_float(r1.y); m[6] = __uint_as_float(r1.z); m[7] = __uint_as_float(r1.w);
+                            m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
+                            const float radius = __uint_as_float(r3.x), zmin = __uint_as_float(r3.y), zmax = __uint_as_float(r3.z),
+                                        phimax = __uint_as_float(r3.w);
+                            if (COUNT) ctr->exact++;
+                            SphereHit sh;
+                            if (intersect_sphere(ray.o, ray.d, tmax, m, radius, zmin, zmax, phimax, &sh)) {
+                                tmax = sh.t; tcull = fminf(tcull, sh.t); found = true; hit.prim_id = r4.x; hit.t = sh.t;
+                                // (u,v) of sphere.rs:382-385
+                                const float th0 = acosf(fminf(fmaxf(zmin / radius, -1.0f), 1.0f));
+                                const float th1 = acosf(fminf(fmaxf(zmax / radius, -1.0f), 1.0f));
+                                const float th = acosf(fminf(fmaxf(sh.p_obj.z / radius, -1.0f), 1.0f));
+                                hit.u = sh.phi / phimax; hit.v = (th - th0) / (th1 - th0);
+                            }
+                        } else {
+                            // triangle record: v0 v1 v2 id ; patch record: p00 p10 p01 p11 id
+                            const bool is_tri = ptype == PM_PRIM_TRI;
+                            const uint32_t unit = pbase + (off + j) * (is_tri ? PM_UNITS_TRI : PM_UNITS_PATCH);
+                            const uint4* r = prims + unit;
+                            const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
+                            const f3 p00 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
+                            const f3 p10 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
+                            const f3 p01 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
+                            bool immediate = true;
+                            if (is_tri && !exact_mode) {
+                                float th;
+                                const int cls = tri_prefilter(ray.o, ray.d, R, D, p00, p10, p01, tcull, &th);
+                                if (cls == 0) immediate = false;
+                                else {
+                                    if (cls == 2) { sure = true; if (!ANY) tcull = th; }
+                                    if (qn < PM_CAND_MAX) { cand[qn * stride] = unit; ++qn; immediate = false; }
+                                }
+                            }
+                            if (immediate) {    // patches; triangles when the queue is full or in the fallback walk
+                                f3 p11 = p01;
+                                uint32_t id = r2.y;
+                                if (!is_tri) {
+                                    const uint4 r3 = r[3];
+                                    p11 = mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
+                                    id = r3.x;
+                                }
+                                if (COUNT) ctr->exact++;
+                                float t, u, v;
+                                if (intersect_patch(ray.o, ray.d, tmax, p00, p10, p01, p11, &t, &u, &v)) {
+                                    tmax = t; found = true; hit.prim_id = id; hit.t = t; hit.u = u; hit.v = v;
+                                    if (!is_tri || exact_mode) tcull = fminf(tcull, t);
+                                }
+                            }
+                        }
+                    }
+                }
+                // ---- descend into the interior children that were hit
+                cur = make_uint2(n1.x, (imask << 8) | perm8(hits & imask, oct));
             }
         }
-        // ---- descend into the interior children that were hit
-        cur = make_uint2(n1.x, (imask << 8) | perm8(hits & imask, oct));
     }
-    return found;
 }
 
 }  // namespace pmd

@@ -92,39 +92,55 @@ __global__ __launch_bounds__(RB) void raygen_kernel(RenderConst rc, SceneArrays 
 // ------------------------------------------------------------------------------------------ traversal
 template <bool COUNT>
 __global__ __launch_bounds__(TB) void closest_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
-                                                     const uint32_t* __restrict__ count, unsigned long long* __restrict__ counters) {
+                                                     const uint32_t* __restrict__ count, uint32_t* __restrict__ work,
+                                                     unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
-    const uint32_t i = xcd_remap_r(blockIdx.x, gridDim.x) * TB + threadIdx.x;
-    if (i >= *count) return;
-    const uint32_t slot = queue[i];
-    if (pa.misc[slot].x == 0xFFFFFFFFu) return;
-    const float4 o = pa.ray_o[slot], d = pa.ray_d[slot];
-    Ray ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(d.x, d.y, d.z); ray.tmax = INFINITY;
-    HitRec h; TravCounters tc = {0u, 0u, 0u};
-    traverse<false, COUNT>(sc.nodes, sc.prims, ray, &h, stack + threadIdx.x, TB, &tc);
-    pa.hit[slot] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
-    if (COUNT) { atomicAdd(&counters[1], (unsigned long long)tc.nodes); atomicAdd(&counters[2], (unsigned long long)tc.prims); }
+    __shared__ uint32_t cand[PM_CAND_MAX * TB];
+    TravCounters tc = {0u, 0u, 0u, 0u, 0u};
+    auto fetch = [&](uint32_t i, Ray* ray) -> bool {
+        const uint32_t slot = queue[i];
+        if (pa.misc[slot].x == 0xFFFFFFFFu) return false;
+        const float4 o = pa.ray_o[slot], d = pa.ray_d[slot];
+        ray->o = mk3(o.x, o.y, o.z); ray->d = mk3(d.x, d.y, d.z); ray->tmax = INFINITY;
+        return true;
+    };
+    auto commit = [&](uint32_t i, bool found, const HitRec& h) {
+        pa.hit[queue[i]] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
+    };
+    trace_persistent<false, COUNT>(sc.nodes, sc.prims, *count, work, stack + threadIdx.x, cand + threadIdx.x, TB, &tc, fetch, commit);
+    if (COUNT) {
+        atomicAdd(&counters[1], (unsigned long long)tc.nodes); atomicAdd(&counters[2], (unsigned long long)tc.prims);
+        atomicAdd(&counters[6], (unsigned long long)tc.exact); if (tc.fallback) atomicAdd(&counters[7], (unsigned long long)tc.fallback);
+    }
     if (tc.overflow) atomicAdd(&counters[3], 1ull);
 }
 template <bool COUNT>
 __global__ __launch_bounds__(TB) void shadow_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ count,
-                                                    unsigned long long* __restrict__ counters) {
+                                                    uint32_t* __restrict__ work, unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
-    const uint32_t i = xcd_remap_r(blockIdx.x, gridDim.x) * TB + threadIdx.x;
-    if (i >= *count) return;
-    const uint32_t slot = pa.shq[i];
-    const float4 o = pa.sh_o[slot], d = pa.sh_d[slot];
-    Ray ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(d.x, d.y, d.z); ray.tmax = o.w;
-    HitRec h; TravCounters tc = {0u, 0u, 0u};
-    const bool occluded = traverse<true, COUNT>(sc.nodes, sc.prims, ray, &h, stack + threadIdx.x, TB, &tc);
-    if (COUNT) { atomicAdd(&counters[4], (unsigned long long)tc.nodes); atomicAdd(&counters[5], (unsigned long long)tc.prims); }
-    if (tc.overflow) atomicAdd(&counters[3], 1ull);
-    if (!occluded) {
-        float4 L = pa.L[slot];
-        const float4 c = pa.sh_L[slot];
-        L.x += c.x; L.y += c.y; L.z += c.z; L.w += c.w;
-        pa.L[slot] = L;
+    __shared__ uint32_t cand[PM_CAND_MAX * TB];
+    TravCounters tc = {0u, 0u, 0u, 0u, 0u};
+    auto fetch = [&](uint32_t i, Ray* ray) -> bool {
+        const uint32_t slot = pa.shq[i];
+        const float4 o = pa.sh_o[slot], d = pa.sh_d[slot];
+        ray->o = mk3(o.x, o.y, o.z); ray->d = mk3(d.x, d.y, d.z); ray->tmax = o.w;
+        return true;
+    };
+    auto commit = [&](uint32_t i, bool occluded, const HitRec&) {
+        if (!occluded) {
+            const uint32_t slot = pa.shq[i];
+            float4 L = pa.L[slot];
+            const float4 c = pa.sh_L[slot];
+            L.x += c.x; L.y += c.y; L.z += c.z; L.w += c.w;
+            pa.L[slot] = L;
+        }
+    };
+    trace_persistent<true, COUNT>(sc.nodes, sc.prims, *count, work, stack + threadIdx.x, cand + threadIdx.x, TB, &tc, fetch, commit);
+    if (COUNT) {
+        atomicAdd(&counters[4], (unsigned long long)tc.nodes); atomicAdd(&counters[5], (unsigned long long)tc.prims);
+        atomicAdd(&counters[6], (unsigned long long)tc.exact); if (tc.fallback) atomicAdd(&counters[7], (unsigned long long)tc.fallback);
     }
+    if (tc.overflow) atomicAdd(&counters[3], 1ull);
 }
 
 // ------------------------------------------------------------------------------------------ shade
@@ -688,21 +704,30 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
         rc.s_base = sb; rc.s_count = std::min(s_per_pass, s1 - sb);
         const uint32_t npaths = (uint32_t)(npix_pad * (size_t)rc.s_count);
         HIPCHK(c, hipMemsetAsync(pa.counts, 0, 2 * (size_t)nb * 4, c->stream));
-        const dim3 gr((npaths + RB - 1) / RB), gt((npaths + TB - 1) / TB);
+        HIPCHK(c, hipMemsetAsync(c->d_work, 0, PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
+        int wslot = 0;      // one work counter per traversal launch (re-zeroed when the slots run out)
+        const dim3 gr((npaths + RB - 1) / RB);
+        const dim3 gt(std::min<uint32_t>((npaths + TB - 1) / TB, (uint32_t)c->n_cu * PM_BLOCKS_PER_CU));
         mark(0);
         hipLaunchKernelGGL(raygen_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, npaths);
         uint32_t *qin = pa.q0, *qout = pa.q1;
         for (int b = 0; b <= p->max_depth; ++b) {
             uint32_t* cnt_in = pa.counts + b; uint32_t* cnt_out = pa.counts + b + 1; uint32_t* cnt_sh = pa.counts + nb + b;
+            if (wslot + 2 > PM_WORK_SLOTS) {   // stream-ordered: every earlier traversal kernel has finished with its counter
+                HIPCHK(c, hipMemsetAsync(c->d_work, 0, PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
+                wslot = 0;
+            }
             mark(1);
-            if (c->counting) hipLaunchKernelGGL(closest_kernel<true>, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_counters);
-            else hipLaunchKernelGGL(closest_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_counters);
+            if (c->counting) hipLaunchKernelGGL(closest_kernel<true>, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_work + wslot, c->d_counters);
+            else hipLaunchKernelGGL(closest_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_work + wslot, c->d_counters);
+            ++wslot;
             mark(2);
             hipLaunchKernelGGL(shade_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, qin, cnt_in, qout, cnt_out, cnt_sh);
             if (p->sample_lights && b < p->max_depth) {
                 mark(3);
-                if (c->counting) hipLaunchKernelGGL(shadow_kernel<true>, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_counters);
-                else hipLaunchKernelGGL(shadow_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_counters);
+                if (c->counting) hipLaunchKernelGGL(shadow_kernel<true>, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_work + wslot, c->d_counters);
+                else hipLaunchKernelGGL(shadow_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_work + wslot, c->d_counters);
+                ++wslot;
             }
             std::swap(qin, qout);
             r->stats.kernels_launched += 3;

@@ -94,6 +94,8 @@ def test_counters_match_cpu_walk_of_same_tree(pm, ora):
     assert c["rays"] == len(rays)
     assert c["nodes_visited"] == cw["nodes_visited"]
     assert c["prims_tested"] == cw["prims_tested"]
+    assert c["exact_tests"] == cw["exact_tests"]
+    assert c["fallback_walks"] == cw["fallback_walks"] == 0
     assert c["stack_overflows"] == 0
     agg.reset_counters()
     sh = pm.scenes.shadow_rays(rays, gpu)
@@ -101,7 +103,7 @@ def test_counters_match_cpu_walk_of_same_tree(pm, ora):
     ca, cwa = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), sh, any_hit=True)
     c = agg.counters()
     assert np.array_equal(ga, ca)
-    assert (c["nodes_visited"], c["prims_tested"]) == (cwa["nodes_visited"], cwa["prims_tested"])
+    assert (c["nodes_visited"], c["prims_tested"], c["exact_tests"]) == (cwa["nodes_visited"], cwa["prims_tested"], cwa["exact_tests"])
     agg.set_counting(False)
 
 
