@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="path workload: skip the C3 closest-hit figure")
     ap.add_argument("--cpu-sample", type=int, default=1 << 21, help="rays in the bounded CPU-baseline sample (trace)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time bound (path)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
+                                                       "several ranks on one GPU)")
     return ap.parse_args()
 
 
@@ -234,6 +236,8 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup):
                    "closest_prims_per_ray": st_c["closest_prims"] / max(1, st_c["closest_rays"]),
                    "shadow_nodes_per_ray": st_c["shadow_nodes"] / max(1, st_c["shadow_rays"]),
                    "shadow_prims_per_ray": st_c["shadow_prims"] / max(1, st_c["shadow_rays"]),
+                   "exact_tests_per_ray": st_c["exact_tests"] / max(1, st_c["closest_rays"] + st_c["shadow_rays"]),
+                   "fallback_walks": st_c["fallback_walks"],
                    "kernel_ms": dict(zip(KERNEL_NAMES, [float(x) for x in ms_k])),
                    "kernel_GBps": dict(zip(KERNEL_NAMES, [float(b / (m * 1e-3) / 1e9) if m > 0 else 0.0
                                                           for b, m in zip(bytes_k, ms_k)]))},
@@ -256,9 +260,13 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the only path (no CPU fallback)")
+    local_rank %= torch.cuda.device_count()       # (rehearsing N ranks on fewer GPUs; a no-op on a full node)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     pm = importlib.import_module("pbrt-rs_amd")
     want_cpu = world == 1 and not args.no_cpu_baseline
 

@@ -185,6 +185,7 @@ typedef struct PmRenderStats {
     uint64_t launches_by_kernel[5];
     /* traversal counters of this render (only with pm_set_counting(ctx, 1)) */
     uint64_t closest_nodes, closest_prims, shadow_nodes, shadow_prims;
+    uint64_t exact_tests, fallback_walks;   /* both ray kinds together */
 } PmRenderStats;
 
 int pm_set_materials(pm_ctx* ctx, const PmMaterial* mats, uint32_t n);

@@ -77,7 +77,8 @@ class PmRenderStats(C.Structure):
                 ("passes", C.c_uint64), ("kernels_launched", C.c_uint64), ("kernel_ms", C.c_double),
                 ("state_bytes_per_path", C.c_double), ("ms_by_kernel", C.c_double * 5),
                 ("launches_by_kernel", C.c_uint64 * 5), ("closest_nodes", C.c_uint64), ("closest_prims", C.c_uint64),
-                ("shadow_nodes", C.c_uint64), ("shadow_prims", C.c_uint64)]
+                ("shadow_nodes", C.c_uint64), ("shadow_prims", C.c_uint64), ("exact_tests", C.c_uint64),
+                ("fallback_walks", C.c_uint64)]
 
 
 PM_SPEC_CONSTANT, PM_SPEC_DENSE, PM_SPEC_RGB_ALBEDO, PM_SPEC_RGB_UNBOUNDED, PM_SPEC_RGB_ILLUMINANT, PM_SPEC_BLACKBODY = range(6)
@@ -136,7 +137,8 @@ SYMBOLS = {
 }
 
 
-def load_library(path=LIB_PATH):
+def load_library(path=None):
+    path = path or os.environ.get("PBRT_MI355_LIB") or LIB_PATH     # override: development builds of the same ABI
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "

@@ -1,15 +1,17 @@
 // C ABI of libpbrt_mi355.so (include/pbrt_mi355.h): context, geometry upload, wide-BVH build,
 // batched closest-hit / any-hit kernels.  gfx950 only.
+#include <cstdlib>
+
 #include "pm_ctx.h"
 #include "pm_device.hpp"
 
 // ------------------------------------------------------------------------------------------ kernels
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const PmWideNode* __restrict__ nodes,
+__global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR void trace_kernel(const PmWideNode* __restrict__ nodes,
                                                             const uint4* __restrict__ prims,
                                                             const PmRay* __restrict__ rays, uint32_t n,
                                                             PmHit* __restrict__ hits, uint8_t* __restrict__ occ,
-                                                            uint32_t* __restrict__ work,
+                                                            uint32_t* __restrict__ work, uint32_t refill,
                                                             unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TRACE_BLOCK];
     __shared__ uint32_t cand[PM_CAND_MAX * TRACE_BLOCK];
@@ -28,7 +30,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const PmWideNode* __
             *reinterpret_cast<float4*>(hits + i) = o;
         }
     };
-    pmd::trace_persistent<ANY, COUNT>(nodes, prims, n, work, stack + threadIdx.x, cand + threadIdx.x, TRACE_BLOCK, &tc, fetch, commit);
+    pmd::trace_persistent<ANY, COUNT>(nodes, prims, n, work, refill, stack + threadIdx.x, cand + threadIdx.x, TRACE_BLOCK, &tc, fetch, commit);
     if (COUNT) {
         // wave-level reduction, one atomic per wave per counter
         unsigned long long nn = tc.nodes, pp = tc.prims, ee = tc.exact, ff = tc.fallback;
@@ -204,6 +206,10 @@ extern "C" int pm_build_accel(pm_ctx* c, int split_method, int max_prims_in_node
         if (pb) HIPCHK(c, hipMemcpy(c->d_prims, c->accel.prims.data(), pb, hipMemcpyHostToDevice));
     }
     c->accel_valid = true;
+    // refill threshold of the persistent traversal waves: walks through a tiny tree all have about the same (short)
+    // length, so refilling early only multiplies the exact-test rounds; deep trees have long-tailed walks.
+    c->refill = c->accel.nodes.size() <= 64 ? 64u : 32u;     // measured: scripts/refill_sweep.sh, profiles/r01/refill_sweep.log
+    if (const char* e = std::getenv("PBRT_MI355_REFILL")) { int v = std::atoi(e); if (v >= 1 && v <= 64) c->refill = (uint32_t)v; }
     if (info) {
         info->n_prims = c->scene.next_prim_id;
         info->n_nodes = (uint32_t)c->accel.nodes.size();
@@ -257,10 +263,10 @@ static int trace_impl(pm_ctx* c, const PmRay* rays, uint64_t n, void* out, size_
         uint8_t* oo = ANY ? (uint8_t*)d_out + b : nullptr;
         if (c->counting)
             hipLaunchKernelGGL((trace_kernel<ANY, true>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_nodes, c->d_prims,
-                               d_rays + b, m, oh, oo, c->d_work + k, c->d_counters);
+                               d_rays + b, m, oh, oo, c->d_work + k, c->refill, c->d_counters);
         else
             hipLaunchKernelGGL((trace_kernel<ANY, false>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_nodes, c->d_prims,
-                               d_rays + b, m, oh, oo, c->d_work + k, c->d_counters);
+                               d_rays + b, m, oh, oo, c->d_work + k, c->refill, c->d_counters);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));

@@ -15,7 +15,14 @@ struct RenderState;   // pm_render.hip
 
 #define TRACE_BLOCK 128
 #define PM_WORK_SLOTS 64
+#ifndef PM_BLOCKS_PER_CU
 #define PM_BLOCKS_PER_CU 8      // persistent traversal grids: 8 blocks x 2 waves per CU = 4 waves per SIMD
+#endif
+#ifdef PM_WAVES_PER_EU
+#define PM_TRAV_ATTR __attribute__((amdgpu_waves_per_eu(PM_WAVES_PER_EU, PM_WAVES_PER_EU)))
+#else
+#define PM_TRAV_ATTR
+#endif
 
 struct pm_ctx {
     int device = 0;
@@ -31,6 +38,7 @@ struct pm_ctx {
     unsigned long long* d_counters = nullptr;   // [1] nodes [2] prims [3] overflow [4] shadow nodes [5] shadow prims [6] exact [7] fallback
     uint32_t* d_work = nullptr;                 // PM_WORK_SLOTS work-item counters of the persistent traversal kernels
     int n_cu = 256;
+    uint32_t refill = 24;                       // idle lanes that trigger a wave refill (chosen in pm_build_accel)
     bool counting = false;
     uint64_t rays_counted = 0;
     float last_ms = 0.0f;

@@ -280,12 +280,11 @@ PMD int tri_prefilter(f3 ro, f3 rd, float R, float D, f3 v0, f3 v1, f3 v2, float
 
 #define PM_CAND_MAX 4
 #define PM_NODE_MARGIN 2.384185791015625e-07f   /* 4 * 2^-24: rounding of the pre-scaled slab evaluation */
-#define PM_REFILL 24                            /* a wave refills its idle lanes when at least this many are idle */
 #define PM_WALK_GUARD (1u << 22)                /* per-ray bound on node steps (a corrupt buffer cannot hang a wave) */
 
 // Rays through the wide BVH, persistent waves.  ANY: intersect_p (is anything hit before ray.tmax); otherwise closest hit.
 //
-// Every wave pulls work items from one global counter: when PM_REFILL or more of its lanes are idle, the lanes whose walk
+// Every wave pulls work items from one global counter: when `refill` or more of its lanes are idle, the lanes whose walk
 // has ended run their exact tests together and commit, then all idle lanes fetch the next items (one atomic per refill).
 // This keeps the lanes of a wave busy although walks differ a lot in length (a wave otherwise runs as long as its
 // longest walk: ~3x the mean node steps on the C3 primary rays, oracle/oracle_api.cpp wave model).
@@ -303,8 +302,8 @@ PMD int tri_prefilter(f3 ro, f3 rd, float R, float D, f3 v0, f3 v1, f3 v2, float
 // candidate queue.
 template <bool ANY, bool COUNT, class FetchFn, class CommitFn>
 PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __restrict__ prims, uint32_t n_items,
-                          uint32_t* __restrict__ work_counter, uint2* lds, uint32_t* cand, int stride, TravCounters* ctr,
-                          FetchFn fetch, CommitFn commit) {
+                          uint32_t* __restrict__ work_counter, uint32_t refill, uint2* lds, uint32_t* cand, int stride,
+                          TravCounters* ctr, FetchFn fetch, CommitFn commit) {
     const float widen = 1.0f + 2.0f * gamma_n(3);
     const uint32_t lane = threadIdx.x & 63u;
     bool active = false;       // this lane is walking a ray
@@ -338,7 +337,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
 
     for (;;) {
         const uint32_t n_idle = (uint32_t)__popcll(__ballot(!active));
-        if (n_idle == 64u || ((more || wnext < wend) && n_idle >= PM_REFILL)) {
+        if (n_idle == 64u || ((more || wnext < wend) && n_idle >= refill)) {
             // ---- lanes whose walk has ended: exact tests of the queued triangles, in the order they were met
             if (finished) {
                 for (uint32_t qi = 0; qi < PM_CAND_MAX; ++qi) {

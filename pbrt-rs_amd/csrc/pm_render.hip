@@ -91,8 +91,8 @@ __global__ __launch_bounds__(RB) void raygen_kernel(RenderConst rc, SceneArrays 
 
 // ------------------------------------------------------------------------------------------ traversal
 template <bool COUNT>
-__global__ __launch_bounds__(TB) void closest_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
-                                                     const uint32_t* __restrict__ count, uint32_t* __restrict__ work,
+__global__ __launch_bounds__(TB) PM_TRAV_ATTR void closest_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
+                                                     const uint32_t* __restrict__ count, uint32_t* __restrict__ work, uint32_t refill,
                                                      unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
     __shared__ uint32_t cand[PM_CAND_MAX * TB];
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(TB) void closest_kernel(SceneArrays sc, PathArrays 
     auto commit = [&](uint32_t i, bool found, const HitRec& h) {
         pa.hit[queue[i]] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
     };
-    trace_persistent<false, COUNT>(sc.nodes, sc.prims, *count, work, stack + threadIdx.x, cand + threadIdx.x, TB, &tc, fetch, commit);
+    trace_persistent<false, COUNT>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB, &tc, fetch, commit);
     if (COUNT) {
         atomicAdd(&counters[1], (unsigned long long)tc.nodes); atomicAdd(&counters[2], (unsigned long long)tc.prims);
         atomicAdd(&counters[6], (unsigned long long)tc.exact); if (tc.fallback) atomicAdd(&counters[7], (unsigned long long)tc.fallback);
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(TB) void closest_kernel(SceneArrays sc, PathArrays 
     if (tc.overflow) atomicAdd(&counters[3], 1ull);
 }
 template <bool COUNT>
-__global__ __launch_bounds__(TB) void shadow_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ count,
-                                                    uint32_t* __restrict__ work, unsigned long long* __restrict__ counters) {
+__global__ __launch_bounds__(TB) PM_TRAV_ATTR void shadow_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ count,
+                                                    uint32_t* __restrict__ work, uint32_t refill, unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
     __shared__ uint32_t cand[PM_CAND_MAX * TB];
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(TB) void shadow_kernel(SceneArrays sc, PathArrays p
             pa.L[slot] = L;
         }
     };
-    trace_persistent<true, COUNT>(sc.nodes, sc.prims, *count, work, stack + threadIdx.x, cand + threadIdx.x, TB, &tc, fetch, commit);
+    trace_persistent<true, COUNT>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB, &tc, fetch, commit);
     if (COUNT) {
         atomicAdd(&counters[4], (unsigned long long)tc.nodes); atomicAdd(&counters[5], (unsigned long long)tc.prims);
         atomicAdd(&counters[6], (unsigned long long)tc.exact); if (tc.fallback) atomicAdd(&counters[7], (unsigned long long)tc.fallback);
@@ -696,7 +696,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     while (r->ev_pool.size() < max_launch + 1) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); r->ev_pool.push_back(e); }
     std::vector<int> ev_class; ev_class.reserve(max_launch);
     auto mark = [&](int cls) { (void)hipEventRecord(r->ev_pool[ev_class.size()], c->stream); ev_class.push_back(cls); };
-    unsigned long long cnt_before[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long cnt_before[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(c, hipMemcpy(cnt_before, c->d_counters, sizeof(cnt_before), hipMemcpyDeviceToHost));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     for (int sb = s0; sb < s1; sb += s_per_pass) {
@@ -718,15 +718,15 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
                 wslot = 0;
             }
             mark(1);
-            if (c->counting) hipLaunchKernelGGL(closest_kernel<true>, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_work + wslot, c->d_counters);
-            else hipLaunchKernelGGL(closest_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_work + wslot, c->d_counters);
+            if (c->counting) hipLaunchKernelGGL(closest_kernel<true>, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_work + wslot, c->refill, c->d_counters);
+            else hipLaunchKernelGGL(closest_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_work + wslot, c->refill, c->d_counters);
             ++wslot;
             mark(2);
             hipLaunchKernelGGL(shade_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, qin, cnt_in, qout, cnt_out, cnt_sh);
             if (p->sample_lights && b < p->max_depth) {
                 mark(3);
-                if (c->counting) hipLaunchKernelGGL(shadow_kernel<true>, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_work + wslot, c->d_counters);
-                else hipLaunchKernelGGL(shadow_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_work + wslot, c->d_counters);
+                if (c->counting) hipLaunchKernelGGL(shadow_kernel<true>, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_work + wslot, c->refill, c->d_counters);
+                else hipLaunchKernelGGL(shadow_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_work + wslot, c->refill, c->d_counters);
                 ++wslot;
             }
             std::swap(qin, qout);
@@ -758,10 +758,11 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     r->stats.kernel_ms = ms; c->last_ms = ms;
     {
-        unsigned long long cnt_after[6];
+        unsigned long long cnt_after[8];
         HIPCHK(c, hipMemcpy(cnt_after, c->d_counters, sizeof(cnt_after), hipMemcpyDeviceToHost));
         r->stats.closest_nodes = cnt_after[1] - cnt_before[1]; r->stats.closest_prims = cnt_after[2] - cnt_before[2];
         r->stats.shadow_nodes = cnt_after[4] - cnt_before[4]; r->stats.shadow_prims = cnt_after[5] - cnt_before[5];
+        r->stats.exact_tests = cnt_after[6] - cnt_before[6]; r->stats.fallback_walks = cnt_after[7] - cnt_before[7];
         if (cnt_after[3] != cnt_before[3]) return fail(c, PM_ERR_STACK_OVERFLOW, "pm_render: traversal stack overflow");
     }
     if (debug_one) {
