@@ -24,6 +24,8 @@ struct PathArrays {
     uint2* misc;          // x: depth | specular << 8 ; y: filter weight bits
     uint32_t *q0, *q1, *shq;
     uint32_t* counts;     // [2 * (max_depth + 2)]: active count per bounce, shadow count per bounce
+    float4* rw_f;         // RandomWalk only: f * |cos| of bounce d of path `slot` at rw_f[d * cap + slot]
+    uint32_t cap;         // slots per array
 };
 struct SceneArrays {
     const PmWideNode* nodes; const uint4* prims;
@@ -169,6 +171,32 @@ __device__ __forceinline__ uint32_t block_append(bool want, uint32_t* __restrict
     return want ? idx : 0xFFFFFFFFu;
 }
 
+// SurfaceInteraction::get_bsdf (core/interaction.rs:186-215, materials/material.rs:122-195) at the sampled wavelengths;
+// may terminate the secondary wavelengths (pdfw is updated in registers and in the path state)
+__device__ __forceinline__ Bsdf make_bsdf(const SceneArrays& sc, const PathArrays& pa, const SurfInt& si, uint32_t prim_id,
+                                          const float* lam, float* pdfw, uint32_t slot) {
+    const DMaterial mat = sc.materials[sc.prim_material[prim_id]];
+    Bsdf bsdf;
+    bsdf.type = mat.type;
+    if (mat.type == PM_MAT_DIFFUSE) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bsdf.refl.v[c] = clampf(spectrum_at(sc.pool, mat.spec, lam[c]), 0.0f, 1.0f);
+        bsdf.eta = 1.0f; bsdf.tr.ax = 0.0f; bsdf.tr.ay = 0.0f;
+    } else {
+        bsdf.refl = spec_c(0.0f);
+        bsdf.eta = spectrum_at(sc.pool, mat.spec, lam[0]);
+        if (mat.spec.kind != PM_SPEC_CONSTANT) {   // SampledWavelengths::terminate_secondary
+            if (!(pdfw[1] == 0.0f && pdfw[2] == 0.0f && pdfw[3] == 0.0f)) { pdfw[0] /= 4.0f; pdfw[1] = 0.0f; pdfw[2] = 0.0f; pdfw[3] = 0.0f; }
+            pa.pdf[slot] = make_float4(pdfw[0], pdfw[1], pdfw[2], pdfw[3]);
+        }
+        float ur = mat.ur, vr = mat.vr;
+        if (mat.remap) { ur = sqrtf(ur); vr = sqrtf(vr); }
+        bsdf.tr.ax = ur; bsdf.tr.ay = vr;
+    }
+    bsdf.fx = norm3(si.dpdus); bsdf.fz = si.ns; bsdf.fy = cross3(bsdf.fz, bsdf.fx);
+    return bsdf;
+}
+
 __global__ __launch_bounds__(RB) void shade_kernel(RenderConst rc, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ qin,
                                                    const uint32_t* __restrict__ count_in, uint32_t* __restrict__ qout,
                                                    uint32_t* __restrict__ count_out, uint32_t* __restrict__ shadow_count) {
@@ -210,26 +238,7 @@ __global__ __launch_bounds__(RB) void shade_kernel(RenderConst rc, SceneArrays s
             SurfInt si;
             if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], ro, rd, hv.y);
             else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w);
-            // ---- BSDF (materials/material.rs:122-195)
-            const DMaterial mat = sc.materials[sc.prim_material[prim_id]];
-            Bsdf bsdf;
-            bsdf.type = mat.type;
-            if (mat.type == PM_MAT_DIFFUSE) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) bsdf.refl.v[c] = clampf(spectrum_at(sc.pool, mat.spec, lam[c]), 0.0f, 1.0f);
-                bsdf.eta = 1.0f; bsdf.tr.ax = 0.0f; bsdf.tr.ay = 0.0f;
-            } else {
-                bsdf.refl = spec_c(0.0f);
-                bsdf.eta = spectrum_at(sc.pool, mat.spec, lam[0]);
-                if (mat.spec.kind != PM_SPEC_CONSTANT) {   // SampledWavelengths::terminate_secondary
-                    if (!(pdfw[1] == 0.0f && pdfw[2] == 0.0f && pdfw[3] == 0.0f)) { pdfw[0] /= 4.0f; pdfw[1] = 0.0f; pdfw[2] = 0.0f; pdfw[3] = 0.0f; }
-                    pa.pdf[slot] = make_float4(pdfw[0], pdfw[1], pdfw[2], pdfw[3]);
-                }
-                float ur = mat.ur, vr = mat.vr;
-                if (mat.remap) { ur = sqrtf(ur); vr = sqrtf(vr); }
-                bsdf.tr.ax = ur; bsdf.tr.ay = vr;
-            }
-            bsdf.fx = norm3(si.dpdus); bsdf.fz = si.ns; bsdf.fy = cross3(bsdf.fz, bsdf.fx);
+            Bsdf bsdf = make_bsdf(sc, pa, si, prim_id, lam, pdfw, slot);
             const f3 wo = -rd;
             const uint4 r4 = pa.rng[slot];
             Rng rng; rng.state = ((unsigned long long)r4.y << 32) | r4.x; rng.inc = ((unsigned long long)r4.w << 32) | r4.z;
@@ -328,6 +337,79 @@ __global__ __launch_bounds__(RB) void shade_kernel(RenderConst rc, SceneArrays s
     if (cont) qout[oi] = slot;
     const uint32_t si_ = block_append(want_shadow, shadow_count, lds_b);
     if (want_shadow) pa.shq[si_] = slot;
+}
+
+// ------------------------------------------------------------------------------------------ shade (RandomWalk)
+// RandomWalkIntegrator::incident_radiance_random_walk (integrators/random_walk.rs:106-173), recursion unrolled: bounce d
+// stores f * |cos| in rw_f[d]; when the walk ends with radiance Le, the result is folded from the deepest bounce outwards
+// exactly as the recursion returns it:  L = 0 + f_d * L / (1 / (4 pi)).
+__global__ __launch_bounds__(RB) void shade_rw_kernel(RenderConst rc, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ qin,
+                                                      const uint32_t* __restrict__ count_in, uint32_t* __restrict__ qout,
+                                                      uint32_t* __restrict__ count_out) {
+    __shared__ uint32_t lds_a[RB / 64 + 1];
+    const uint32_t i = blockIdx.x * RB + threadIdx.x;
+    const uint32_t n_in = *count_in;
+    if (blockIdx.x * RB >= n_in) return;             // whole block idle (uniform exit, before any barrier)
+    bool cont = false;
+    uint32_t slot = 0;
+    const bool live = i < n_in;
+    if (live) slot = qin[i];
+    const uint2 misc = live ? pa.misc[slot] : make_uint2(0xFFFFFFFFu, 0u);
+    if (live && misc.x != 0xFFFFFFFFu) {
+        const float4 hv = pa.hit[slot];
+        const uint32_t prim_id = __float_as_uint(hv.x);
+        const float4 l4 = pa.lambda[slot];
+        const float4 p4 = pa.pdf[slot];
+        const float lam[4] = {l4.x, l4.y, l4.z, l4.w};
+        float pdfw[4] = {p4.x, p4.y, p4.z, p4.w};
+        const int depth = (int)(misc.x & 0xFFu);
+        float Lr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        bool done = true;
+        if (prim_id == 0xFFFFFFFFu) {
+            for (int k = 0; k < rc.n_infinite; ++k) {       // Sum::sum from the zero spectrum
+                const Spec4 le = light_L(sc, sc.lights[sc.infinite[k]], lam);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Lr[c] += le.v[c];
+            }
+        } else if (depth != rc.max_depth) {
+            const float4 ro4 = pa.ray_o[slot], rd4 = pa.ray_d[slot];
+            const f3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
+            const uint32_t ref = sc.prim_ref[prim_id];
+            SurfInt si;
+            if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], ro, rd, hv.y);
+            else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w);
+            const Bsdf bsdf = make_bsdf(sc, pa, si, prim_id, lam, pdfw, slot);
+            const f3 wo = -rd;
+            const uint4 r4 = pa.rng[slot];
+            Rng rng; rng.state = ((unsigned long long)r4.y << 32) | r4.x; rng.inc = ((unsigned long long)r4.w << 32) | r4.z;
+            f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
+            pa.rng[slot] = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), (uint32_t)rng.inc, (uint32_t)(rng.inc >> 32));
+            const f3 wp = sample_uniform_sphere(u2);
+            Spec4 f = bsdf_eval(bsdf, wo, wp);
+            if (!spec_zero(f)) {
+                const float ad = fabsf(dot3(wp, si.ns));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) f.v[c] *= ad;
+                pa.rw_f[(size_t)depth * pa.cap + slot] = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
+                const f3 no = offset_ray_origin(si, wp);
+                pa.ray_o[slot] = make_float4(no.x, no.y, no.z, 0.f);
+                pa.ray_d[slot] = make_float4(wp.x, wp.y, wp.z, 0.f);
+                pa.misc[slot] = make_uint2((uint32_t)(depth + 1), misc.y);
+                cont = true; done = false;
+            }
+        }
+        if (done) {
+            const float pdf = 1.0f / (4.0f * 3.14159265358979323846f);
+            for (int k = depth - 1; k >= 0; --k) {
+                const float4 f = pa.rw_f[(size_t)k * pa.cap + slot];
+                Lr[0] = 0.0f + f.x * Lr[0] / pdf; Lr[1] = 0.0f + f.y * Lr[1] / pdf;
+                Lr[2] = 0.0f + f.z * Lr[2] / pdf; Lr[3] = 0.0f + f.w * Lr[3] / pdf;
+            }
+            pa.L[slot] = make_float4(Lr[0], Lr[1], Lr[2], Lr[3]);
+        }
+    }
+    const uint32_t oi = block_append(cont, count_out, lds_a);
+    if (cont) qout[oi] = slot;
 }
 
 // ------------------------------------------------------------------------------------------ accumulate
@@ -622,8 +704,8 @@ static int upload_scene(pm_ctx* c, RenderState* r) {
     return PM_OK;
 }
 
-static int ensure_paths(pm_ctx* c, RenderState* r, size_t npaths, int max_depth) {
-    if (r->pa_cap >= npaths && r->pa_depth >= max_depth) return PM_OK;
+static int ensure_paths(pm_ctx* c, RenderState* r, size_t npaths, int max_depth, bool random_walk) {
+    if (r->pa_cap >= npaths && r->pa_depth >= max_depth && (!random_walk || r->pa.rw_f)) return PM_OK;
     for (void* p : r->pa_allocs) HIPCHK(c, hipFree(p));
     r->pa_allocs.clear(); r->pa_cap = 0;
     auto al = [&](void** p, size_t bytes) -> int { HIPCHK(c, hipMalloc(p, bytes)); r->pa_allocs.push_back(*p); return PM_OK; };
@@ -637,6 +719,8 @@ static int ensure_paths(pm_ctx* c, RenderState* r, size_t npaths, int max_depth)
     if ((rc = al((void**)&pa.q1, npaths * 4))) return rc;
     if ((rc = al((void**)&pa.shq, npaths * 4))) return rc;
     if ((rc = al((void**)&pa.counts, 2 * (size_t)(max_depth + 2) * 4))) return rc;
+    pa.rw_f = nullptr; pa.cap = (uint32_t)npaths;
+    if (random_walk && (rc = al((void**)&pa.rw_f, (size_t)std::max(1, max_depth) * npaths * sizeof(float4)))) return rc;
     r->pa_cap = npaths; r->pa_depth = max_depth;
     return PM_OK;
 }
@@ -647,8 +731,8 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     if (!c->accel_valid) return fail(c, PM_ERR_NO_ACCEL, "pm_render: pm_build_accel has not been called");
     RenderState* r = rs(c);
     if (!r->have_cam || !r->have_film) return fail(c, PM_ERR_INVALID, "pm_render: camera and film must be set");
-    if (p->integrator == PM_INTEGRATOR_RANDOM_WALK) return fail(c, PM_ERR_UNSUPPORTED, "pm_render: RandomWalkIntegrator is not on the GPU path yet");
-    if (p->integrator != PM_INTEGRATOR_SIMPLE_PATH) return fail(c, PM_ERR_INVALID, "pm_render: unknown integrator");
+    if (p->integrator != PM_INTEGRATOR_SIMPLE_PATH && p->integrator != PM_INTEGRATOR_RANDOM_WALK)
+        return fail(c, PM_ERR_INVALID, "pm_render: unknown integrator");
     if (p->max_depth < 0 || p->max_depth > 254) return fail(c, PM_ERR_INVALID, "pm_render: max_depth out of range");
     const int* pb = r->film.pixel_bounds;
     int x0 = p->window[0], y0 = p->window[1], x1 = p->window[2], y1 = p->window[3], s0 = p->s0, s1 = p->s1;
@@ -669,7 +753,8 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     int s_per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)(s1 - s0), target / npix_pad));
     const size_t max_paths = npix_pad * (size_t)s_per_pass;
     if (max_paths > 0x7FFFFFFFull) return fail(c, PM_ERR_INVALID, "pm_render: window too large for one pass");
-    if ((rcode = ensure_paths(c, r, max_paths, p->max_depth))) return rcode;
+    const bool random_walk = p->integrator == PM_INTEGRATOR_RANDOM_WALK;
+    if ((rcode = ensure_paths(c, r, max_paths, p->max_depth, random_walk))) return rcode;
 
     RenderConst rc{};
     std::memcpy(rc.cfr, r->cam.camera_from_raster, 64); std::memcpy(rc.rfc, r->cam.render_from_camera, 48);
@@ -722,8 +807,9 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
             else hipLaunchKernelGGL(closest_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_work + wslot, c->refill, c->d_counters);
             ++wslot;
             mark(2);
-            hipLaunchKernelGGL(shade_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, qin, cnt_in, qout, cnt_out, cnt_sh);
-            if (p->sample_lights && b < p->max_depth) {
+            if (random_walk) hipLaunchKernelGGL(shade_rw_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, qin, cnt_in, qout, cnt_out);
+            else hipLaunchKernelGGL(shade_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, qin, cnt_in, qout, cnt_out, cnt_sh);
+            if (!random_walk && p->sample_lights && b < p->max_depth) {
                 mark(3);
                 if (c->counting) hipLaunchKernelGGL(shadow_kernel<true>, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_work + wslot, c->refill, c->d_counters);
                 else hipLaunchKernelGGL(shadow_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_work + wslot, c->refill, c->d_counters);

@@ -27,9 +27,10 @@ def oracle_renderer_from(sd, ora, split=None):
     return r
 
 
-def render_params(pmod, sd, spp, max_depth=5, sample_lights=True, sample_bsdf=True, seed=0, window=None, samples=None):
+def render_params(pmod, sd, spp, max_depth=5, sample_lights=True, sample_bsdf=True, seed=0, window=None, samples=None,
+                  integrator=None):
     p = pmod._capi.PmRenderParams()
-    p.integrator = pmod._capi.PM_INTEGRATOR_SIMPLE_PATH
+    p.integrator = pmod._capi.PM_INTEGRATOR_SIMPLE_PATH if integrator is None else integrator
     p.max_depth, p.sample_lights, p.sample_bsdf, p.spp, p.seed = max_depth, int(sample_lights), int(sample_bsdf), spp, seed
     p.window[:] = list(window if window is not None else sd.film["pixel_bounds"])
     p.s0, p.s1 = samples if samples is not None else (0, spp)

@@ -91,6 +91,34 @@ def test_no_light_sampling_and_uniform_bsdf_sampling(pm, ora):
         assert frac >= 0.985, (sl, sb, frac)
 
 
+def test_random_walk_integrator(pm, ora):
+    """RandomWalkIntegrator (integrators/random_walk.rs:106-173): uniform-sphere bounces, infinite lights on a miss, no
+    next-event estimation.  The GPU unrolls the recursion but folds the result in the recursion's own order, so a sample
+    differs from the oracle only through sin/cos in sample_uniform_sphere (same tolerances as the path integrator)."""
+    res, spp, depth = (48, 48), 16, 4
+    sd = pm.scenes.main_rs_scene(res)
+    RW = pm._capi.PM_INTEGRATOR_RANDOM_WALK
+    integ = pm.WavefrontIntegrator(depth, True, True, sd, spp, integrator=RW)
+    oren = helpers.oracle_renderer_from(sd, ora)
+    params = helpers.render_params(pm, sd, spp, depth, integrator=RW)
+    frac = _check_samples(integ, oren, params, res, spp, n=300, seed=3)
+    assert frac >= 0.99, f"only {frac:.3f} of the samples agree"
+    st = integ.render()
+    oc = oren.render(params, 8)
+    assert st["shadow_rays"] == oc["shadow_rays"] == 0
+    assert abs(st["closest_rays"] - oc["closest_rays"]) <= 2e-3 * oc["closest_rays"]
+    gi, oi = integ.image(), oren.image()
+    assert np.isfinite(gi).all() and gi.mean() > 0
+    assert abs(gi.mean() - oi.mean()) <= 5e-3 * abs(oi.mean())
+    assert helpers.rel_rmse(gi, oi) <= 3e-2
+    # depth 0: only directly visible infinite lights
+    integ0 = pm.WavefrontIntegrator(0, True, True, sd, 4, integrator=RW)
+    integ0.render()
+    oren.clear()
+    oren.render(helpers.render_params(pm, sd, 4, 0, integrator=RW), 4)
+    np.testing.assert_allclose(integ0.image(), oren.image(), rtol=2e-5, atol=1e-7)
+
+
 def test_window_and_sample_split_are_bit_identical(pm, ora):
     res, spp = (40, 24), 8       # deliberately not a multiple of the 8x8 tile in y? (24 is; 40 is) -> also use odd window
     sd = pm.scenes.main_rs_scene(res)
