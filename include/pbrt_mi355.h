@@ -83,7 +83,9 @@ const char* pm_last_error(pm_ctx* ctx);   /* valid until the next call on ctx */
  * *first_prim_id receives the id of the first primitive added by the call. */
 int pm_add_spheres(pm_ctx* ctx, const PmSphere* spheres, uint32_t n, uint32_t* first_prim_id);
 /* shapes/bilinear_patch.rs:630-685 BilinearPatchMesh::new — positions already in render space,
- * 4 indices per patch in (p00,p10,p01,p11) order. Vertex normals are not supported yet (must be NULL). */
+ * 4 indices per patch in (p00,p10,p01,p11) order.  normals_or_null: one shading normal per vertex (n_vert x 3), already in
+ * render space and already negated for reverse_orientation, as BilinearPatchMesh::new leaves them (bilinear_patch.rs:660-671;
+ * the reference asserts normals.len() == indices.len() but indexes them by vertex id - here they are per vertex). */
 int pm_add_patch_mesh(pm_ctx* ctx, const float* pos_xyz, uint32_t n_vert, const uint32_t* idx4, uint32_t n_patch,
                       const float* normals_or_null, int reverse_orientation, int transform_swaps_handedness,
                       uint32_t* first_prim_id);

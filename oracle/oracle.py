@@ -40,6 +40,7 @@ def lib():
             "ora_scene_create": (p, []), "ora_scene_destroy": (None, [p]),
             "ora_add_sphere": (u32, [p, f, f, f, f, p, p, i]),
             "ora_add_patch_mesh": (u32, [p, p, u32, p, u32, i, i]),
+            "ora_add_patch_mesh_n": (u32, [p, p, u32, p, u32, p, i, i]),
             "ora_add_triangle_mesh": (u32, [p, p, u32, p, u32]),
             "ora_build": (i, [p, i, i]), "ora_scene_bounds": (None, [p, p]),
             "ora_trace_closest": (None, [p, p, u64, p, p, i, i]),
@@ -79,10 +80,12 @@ class Scene:
         a, b = _f32(rfo).reshape(16), _f32(ofr).reshape(16)
         return self._l.ora_add_sphere(self._h, radius, z_min, z_max, phi_max_deg, a.ctypes.data, b.ctypes.data, int(reverse))
 
-    def add_patch_mesh(self, positions, indices, reverse=False, swaps=False):
+    def add_patch_mesh(self, positions, indices, reverse=False, swaps=False, normals=None):
         pos = _f32(positions).reshape(-1, 3)
         idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 4)
-        return self._l.ora_add_patch_mesh(self._h, pos.ctypes.data, len(pos), idx.ctypes.data, len(idx), int(reverse), int(swaps))
+        nrm = None if normals is None else _f32(normals).reshape(-1, 3)
+        return self._l.ora_add_patch_mesh_n(self._h, pos.ctypes.data, len(pos), idx.ctypes.data, len(idx),
+                                            None if nrm is None else nrm.ctypes.data, int(reverse), int(swaps))
 
     def add_triangle_mesh(self, positions, indices):
         pos = _f32(positions).reshape(-1, 3)

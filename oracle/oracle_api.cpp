@@ -66,8 +66,16 @@ uint32_t ora_add_sphere(OraScene* s, float radius, float z_min, float z_max, flo
     return p.id;
 }
 // positions are already in render space (BilinearPatchMesh::new transforms them, bilinear_patch.rs:649-655)
+uint32_t ora_add_patch_mesh_n(OraScene* s, const float* pos, uint32_t n_vert, const uint32_t* idx4, uint32_t n_patch,
+                              const float* normals, int reverse_orientation, int transform_swaps_handedness);
 uint32_t ora_add_patch_mesh(OraScene* s, const float* pos, uint32_t n_vert, const uint32_t* idx4, uint32_t n_patch,
                             int reverse_orientation, int transform_swaps_handedness) {
+    return ora_add_patch_mesh_n(s, pos, n_vert, idx4, n_patch, nullptr, reverse_orientation, transform_swaps_handedness);
+}
+// `normals`: one per vertex, already in render space and already negated for reverse_orientation, as
+// BilinearPatchMesh::new leaves them (bilinear_patch.rs:660-671); may be null
+uint32_t ora_add_patch_mesh_n(OraScene* s, const float* pos, uint32_t n_vert, const uint32_t* idx4, uint32_t n_patch,
+                              const float* normals, int reverse_orientation, int transform_swaps_handedness) {
     (void)n_vert;
     uint32_t first = s->next_id;
     for (uint32_t i = 0; i < n_patch; ++i) {
@@ -75,6 +83,11 @@ uint32_t ora_add_patch_mesh(OraScene* s, const float* pos, uint32_t n_vert, cons
         auto P = [&](uint32_t k) { return V3(pos[3 * k], pos[3 * k + 1], pos[3 * k + 2]); };
         pt.p00 = P(idx4[4 * i]); pt.p10 = P(idx4[4 * i + 1]); pt.p01 = P(idx4[4 * i + 2]); pt.p11 = P(idx4[4 * i + 3]);
         pt.flip_normal = (reverse_orientation != 0) ^ (transform_swaps_handedness != 0);
+        if (normals) {
+            auto N = [&](uint32_t k) { return V3(normals[3 * k], normals[3 * k + 1], normals[3 * k + 2]); };
+            pt.has_normals = true;
+            pt.n00 = N(idx4[4 * i]); pt.n10 = N(idx4[4 * i + 1]); pt.n01 = N(idx4[4 * i + 2]); pt.n11 = N(idx4[4 * i + 3]);
+        }
         s->sc.patches.push_back(pt);
         s->sc.prims.push_back(Prim{PRIM_PATCH, (uint32_t)s->sc.patches.size() - 1, s->next_id++});
     }

@@ -237,7 +237,20 @@ static inline SurfInt sphere_interaction(const Sphere& s, const Hit& h) {   // s
     si.prim_id = h.prim_id;
     return si;
 }
-static inline SurfInt patch_interaction(const Patch& p, const Hit& h) {     // bilinear_patch.rs:86-167 (no vertex normals)
+// Transform::rotate_from_to (core/transform.rs:180-201), upper 3x3 only (it is applied to vectors)
+static inline void rotate_from_to(V3 from, V3 to, float m[3][3]) {
+    V3 refl;
+    if (std::fabs(from.x) < 0.72f && std::fabs(to.x) < 0.72f) refl = V3(1, 0, 0);
+    else if (std::fabs(from.y) < 0.72f && std::fabs(to.y) < 0.72f) refl = V3(0, 1, 0);
+    else refl = V3(0, 0, 1);
+    V3 u = refl - from, v = refl - to;
+    const float ua[3] = {u.x, u.y, u.z}, va[3] = {v.x, v.y, v.z};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            m[i][j] = (i == j ? 1.0f : 0.0f) - 2.0f / dot(u, u) * ua[i] * ua[j] - 2.0f / dot(v, v) * va[i] * va[j] +
+                      4.0f * dot(u, v) / (dot(u, u) * dot(v, v)) * va[i] * ua[j];
+}
+static inline SurfInt patch_interaction(const Patch& p, const Hit& h) {     // bilinear_patch.rs:86-167
     float u = h.u, v = h.v;
     V3 pt = vlerp(vlerp(p.p00, p.p01, v), vlerp(p.p10, p.p11, v), u);
     V3 dpdu = vlerp(p.p10, p.p11, v) - vlerp(p.p00, p.p01, v);
@@ -249,6 +262,19 @@ static inline SurfInt patch_interaction(const Patch& p, const Hit& h) {     // b
     SurfInt si;
     si.pi = V3fi::with_err(pt, perr);
     si.n = n; si.ns = n; si.dpdus = dpdu; si.prim_id = h.prim_id;
+    if (p.has_normals) {      // bilinear_patch.rs:150-164 + SurfaceInteraction::set_shading_geometry(.., true) (interaction.rs:134-158)
+        V3 ns = vlerp(vlerp(p.n00, p.n01, v), vlerp(p.n10, p.n11, v), u);
+        if (length_squared(ns) > 0.0f) {
+            ns = normalized(ns);
+            float rot[3][3];
+            rotate_from_to(normalized(si.n), ns, rot);
+            si.n = face_forward(si.n, ns);
+            si.ns = ns;
+            si.dpdus = V3(rot[0][0] * dpdu.x + rot[0][1] * dpdu.y + rot[0][2] * dpdu.z,
+                          rot[1][0] * dpdu.x + rot[1][1] * dpdu.y + rot[1][2] * dpdu.z,
+                          rot[2][0] * dpdu.x + rot[2][1] * dpdu.y + rot[2][2] * dpdu.z);
+        }
+    }
     return si;
 }
 

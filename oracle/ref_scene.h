@@ -41,6 +41,8 @@ static inline Sphere make_sphere(float radius, float z_min, float z_max, float p
 struct Patch {             // resolved corner positions + mesh flags
     V3 p00, p10, p01, p11;
     bool flip_normal;      // reverse_orientation ^ transform_swaps_handedness
+    bool has_normals = false;
+    V3 n00, n10, n01, n11; // vertex normals in render space (BilinearPatchMesh::vertex_normals)
 };
 
 struct Prim {

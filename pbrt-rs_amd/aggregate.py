@@ -34,9 +34,14 @@ class Sphere:
 class BilinearPatchMesh:
     """BilinearPatchMesh::new (src/shapes/bilinear_patch.rs:631-685); positions in render space."""
 
-    def __init__(self, positions, indices, reverse_orientation=False, transform_swaps_handedness=False):
+    def __init__(self, positions, indices, reverse_orientation=False, transform_swaps_handedness=False, normals=None):
         self.positions = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
         self.indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 4)
+        # one shading normal per vertex, in render space, already negated when reverse_orientation (as the
+        # reference's constructor leaves them)
+        self.normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+        if self.normals is not None and len(self.normals) != len(self.positions):
+            raise ValueError("normals must hold one normal per vertex")
         self.reverse_orientation = bool(reverse_orientation)
         self.transform_swaps_handedness = bool(transform_swaps_handedness)
 
@@ -83,7 +88,8 @@ class GpuAggregate:
                 self._check(self._lib.pm_add_spheres(self._h, C.byref(s), 1, C.byref(first)))
             elif isinstance(p, BilinearPatchMesh):
                 self._check(self._lib.pm_add_patch_mesh(
-                    self._h, p.positions.ctypes.data, len(p.positions), p.indices.ctypes.data, len(p.indices), None,
+                    self._h, p.positions.ctypes.data, len(p.positions), p.indices.ctypes.data, len(p.indices),
+                    None if p.normals is None else p.normals.ctypes.data,
                     int(p.reverse_orientation), int(p.transform_swaps_handedness), C.byref(first)))
             elif isinstance(p, TriangleMesh):
                 self._check(self._lib.pm_add_triangle_mesh(

@@ -18,6 +18,8 @@ struct HostSphere {
 };
 struct HostPatch {
     float p[4][3];      // p00 p10 p01 p11
+    float n[4][3];      // vertex normals (render space), valid when has_normals
+    bool has_normals = false;
     bool flip_normal;
     uint32_t prim_id;
     Box bounds;

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(RB) void shade_kernel(RenderConst rc, SceneArrays s
             const uint32_t ref = sc.prim_ref[prim_id];
             SurfInt si;
             if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], ro, rd, hv.y);
-            else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w);
+            else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
             Bsdf bsdf = make_bsdf(sc, pa, si, prim_id, lam, pdfw, slot);
             const f3 wo = -rd;
             const uint4 r4 = pa.rng[slot];
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(RB) void shade_rw_kernel(RenderConst rc, SceneArray
             const uint32_t ref = sc.prim_ref[prim_id];
             SurfInt si;
             if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], ro, rd, hv.y);
-            else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w);
+            else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
             const Bsdf bsdf = make_bsdf(sc, pa, si, prim_id, lam, pdfw, slot);
             const f3 wo = -rd;
             const uint4 r4 = pa.rng[slot];
@@ -677,6 +677,10 @@ static int upload_scene(pm_ctx* c, RenderState* r) {
     sp.reserve(c->scene.patches.size() + c->scene.tris.size());
     for (const auto& p : c->scene.patches) {
         DShadePatch d{}; std::memcpy(d.p, p.p, 48); d.flags = p.flip_normal ? 1u : 0u;
+        if (p.has_normals) {
+            d.flags |= 2u; d.nrm_off = (uint32_t)pool.size();
+            pool.insert(pool.end(), &p.n[0][0], &p.n[0][0] + 12);
+        }
         ref[p.prim_id] = ((uint32_t)PM_PRIM_PATCH << 30) | (uint32_t)sp.size(); sp.push_back(d);
     }
     for (const auto& t : c->scene.tris) {

@@ -178,7 +178,7 @@ PMD float sample_tent(float u, float r) {
 
 // ---------------------------------------------------------------------------------------- render constants
 struct DFilter { int kind; float rx, ry; int nx, ny; int vals, cond_cdf, cond_int, marg_func, marg_cdf; float marg_int; };
-struct DShadePatch { float p[12]; uint32_t flags; uint32_t pad[3]; };                       // 64 B
+struct DShadePatch { float p[12]; uint32_t flags; uint32_t nrm_off; uint32_t pad[2]; };     // 64 B; flags bit 0 flip normal, bit 1 vertex normals (12 floats at pool[nrm_off])
 struct DShadeSphere { float rfo[12]; float ofr[12]; float radius, z_min, z_max, phi_max, th_min, th_max; uint32_t flags; uint32_t pad; };  // 128 B
 
 struct RenderConst {
@@ -258,7 +258,27 @@ PMD f3 offset_ray_origin(const SurfInt& si, f3 w) {   // core/ray.rs:47-66
 }
 PMD f3 si_p(const SurfInt& si) { return mk3(iv_mid(si.px), iv_mid(si.py), iv_mid(si.pz)); }
 
-PMD SurfInt patch_interaction(const DShadePatch& sp, float u, float v) {
+// Transform::rotate_from_to (core/transform.rs:180-201) applied to a vector
+PMD f3 rotate_from_to_apply(f3 from, f3 to, f3 x) {
+    f3 refl;
+    if (fabsf(from.x) < 0.72f && fabsf(to.x) < 0.72f) refl = mk3(1.f, 0.f, 0.f);
+    else if (fabsf(from.y) < 0.72f && fabsf(to.y) < 0.72f) refl = mk3(0.f, 1.f, 0.f);
+    else refl = mk3(0.f, 0.f, 1.f);
+    const f3 u = refl - from, v = refl - to;
+    const float ua[3] = {u.x, u.y, u.z}, va[3] = {v.x, v.y, v.z};
+    const float uu = dot3(u, u), vv = dot3(v, v), uv = dot3(u, v);
+    float r[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float m[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            m[j] = (i == j ? 1.0f : 0.0f) - 2.0f / uu * ua[i] * ua[j] - 2.0f / vv * va[i] * va[j] + 4.0f * uv / (uu * vv) * va[i] * ua[j];
+        r[i] = m[0] * x.x + m[1] * x.y + m[2] * x.z;
+    }
+    return mk3(r[0], r[1], r[2]);
+}
+PMD SurfInt patch_interaction(const DShadePatch& sp, float u, float v, const float* __restrict__ pool) {
     const f3 p00 = mk3(sp.p[0], sp.p[1], sp.p[2]), p10 = mk3(sp.p[3], sp.p[4], sp.p[5]);
     const f3 p01 = mk3(sp.p[6], sp.p[7], sp.p[8]), p11 = mk3(sp.p[9], sp.p[10], sp.p[11]);
     const f3 pt = lerp3(lerp3(p00, p01, v), lerp3(p10, p11, v), u);
@@ -271,6 +291,17 @@ PMD SurfInt patch_interaction(const DShadePatch& sp, float u, float v) {
     SurfInt si;
     si.px = iv_err(pt.x, perr.x); si.py = iv_err(pt.y, perr.y); si.pz = iv_err(pt.z, perr.z);
     si.n = n; si.ns = n; si.dpdus = dpdu;
+    if (sp.flags & 2u) {      // bilinear_patch.rs:150-164 + set_shading_geometry(.., orientation_is_authoritative = true)
+        const float* q = pool + sp.nrm_off;
+        const f3 n00 = mk3(q[0], q[1], q[2]), n10 = mk3(q[3], q[4], q[5]), n01 = mk3(q[6], q[7], q[8]), n11 = mk3(q[9], q[10], q[11]);
+        f3 ns = lerp3(lerp3(n00, n01, v), lerp3(n10, n11, v), u);
+        if (dot3(ns, ns) > 0.0f) {
+            ns = norm3(ns);
+            si.dpdus = rotate_from_to_apply(norm3(si.n), ns, dpdu);
+            if (__float_as_uint(dot3(si.n, ns)) >> 31) si.n = -si.n;     // Normal3f::face_forward: sign bit of the dot product
+            si.ns = ns;
+        }
+    }
     return si;
 }
 PMD f3 xf_normal12(const float* mi, f3 n) {   // Transform * Normal3f with the INVERSE matrix rows in mi

@@ -149,6 +149,30 @@ def main_rs_scene(resolution=(400, 400), spectra=None):
     return sd
 
 
+def shading_normal_scene(resolution=(64, 64), grid=6, spectra=None):
+    """main.rs scene whose floor is a grid x grid BilinearPatchMesh WITH vertex normals (a rippled shading normal over a
+    flat quad mesh): exercises BilinearPatch::interaction_from_intersection's shading-geometry branch."""
+    from . import host
+    from .aggregate import BilinearPatchMesh
+    sd = main_rs_scene(resolution, spectra)
+    xs = np.linspace(-6.0, 6.0, grid + 1, dtype=np.float32)
+    X, Y = np.meshgrid(xs, xs, indexing="xy")
+    world = np.stack([X.reshape(-1), Y.reshape(-1), np.full(X.size, -1.0, np.float32)], axis=1)
+    floor_xf = sd.render_from_world
+    pos = _xf_points(floor_xf.m, world)
+    nrm = np.stack([0.35 * np.sin(1.7 * world[:, 0]), 0.35 * np.cos(1.3 * world[:, 1]), np.ones(len(world))], axis=1)
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)     # render_from_world is a translation
+    idx = []
+    for j in range(grid):
+        for i in range(grid):
+            a = j * (grid + 1) + i
+            idx.append([a, a + 1, a + grid + 1, a + grid + 2])       # p00 p10 p01 p11
+    sd.prims[1] = BilinearPatchMesh(pos, idx, normals=nrm)
+    mats = sd.prim_materials
+    sd.prim_materials = [mats[0]] + [mats[1]] * (grid * grid) + mats[2:]
+    return sd
+
+
 def cornell_scene(resolution=(1024, 1024), spectra=None, glass_sphere=True):
     """C2: a Cornell box built from triangles (walls, tall box, short box), lit by a PointLight just under the
     ceiling (the reference has no area light, lights/base.rs:18-22), seen through a PerspectiveCamera.

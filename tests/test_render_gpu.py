@@ -91,6 +91,27 @@ def test_no_light_sampling_and_uniform_bsdf_sampling(pm, ora):
         assert frac >= 0.985, (sl, sb, frac)
 
 
+def test_patch_mesh_with_vertex_normals(pm, ora):
+    """shading normals: lerped vertex normals, Transform::rotate_from_to of dpdu, geometric normal flipped to the shading
+    side (bilinear_patch.rs:150-164, interaction.rs:134-158)"""
+    res, spp = (64, 64), 8
+    sd = pm.scenes.shading_normal_scene(res)
+    integ, oren, params = _pair(pm, ora, sd, spp)
+    frac = _check_samples(integ, oren, params, res, spp, n=400, seed=11)
+    assert frac >= 0.99, f"only {frac:.3f} of the samples agree"
+    integ.render()
+    oren.render(params, 8)
+    gi, oi = integ.image(), oren.image()
+    assert abs(gi.mean() - oi.mean()) <= 3e-3 * abs(oi.mean())
+    assert helpers.rel_rmse(gi, oi) <= 3e-2
+    # and the normals matter: the same mesh without them renders a different image
+    flat = pm.scenes.shading_normal_scene(res)
+    flat.prims[1] = pm.BilinearPatchMesh(flat.prims[1].positions, flat.prims[1].indices)
+    i2 = pm.WavefrontIntegrator(5, True, True, flat, spp)
+    i2.render()
+    assert helpers.rel_rmse(i2.image(), gi) > 5e-2
+
+
 def test_random_walk_integrator(pm, ora):
     """RandomWalkIntegrator (integrators/random_walk.rs:106-173): uniform-sphere bounces, infinite lights on a miss, no
     next-event estimation.  The GPU unrolls the recursion but folds the result in the recursion's own order, so a sample
