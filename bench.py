@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="path", choices=["path", "trace"])
+    ap.add_argument("--workload", default="path", choices=["path", "trace", "c4"])
     ap.add_argument("--res", type=int, default=None, help="image side (path: 1024, trace: 4096)")
     ap.add_argument("--spp", type=int, default=64, help="samples per pixel per GPU (path workload)")
     ap.add_argument("--max-depth", type=int, default=5)
@@ -174,13 +174,28 @@ def kernel_bytes(st, info, sd):
     return b
 
 
+def note(msg):
+    """progress on stderr (stdout carries only the JSON line)"""
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup):
-    res = args.res or 1024
-    spp_total = args.spp * world
-    sd = pm.scenes.cornell_scene((res, res))
+    note("building scene")
+    if args.workload == "c4":      # BASELINE.json configs[3]: 20,971,520 triangles, 3840x2160 @ 256 spp, uniform sky
+        rw, rh = (args.res or 3840), ((args.res or 3840) * 9) // 16
+        n_blobs = args.blobs if args.blobs != 1024 else 20480
+        sd = pm.scenes.blob_sky_scene(n_blobs, (rw, rh))
+        spp = args.spp if args.spp != 64 else 256
+        name = f"C4 {n_blobs * 1024} diffuse triangles under a uniform sky: {rw}x{rh} @ {spp} spp per GPU"
+    else:
+        rw = rh = args.res or 1024
+        sd = pm.scenes.cornell_scene((rw, rh))
+        spp = args.spp
+        name = f"C2 Cornell box path tracing: {rw}x{rh} @ {spp} spp per GPU"
+    spp_total = spp * world
     integ = pm.WavefrontIntegrator(args.max_depth, True, True, sd, spp_total, seed=0, device_id=local_rank)
     s0, s1 = pm.distributed.shard_samples(spp_total, rank, world)
-    film = torch.empty((res, res, 4), dtype=torch.float64, device="cuda")
+    film = torch.empty((rh, rw, 4), dtype=torch.float64, device="cuda")
 
     def step():
         integ.clear()
@@ -196,11 +211,13 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup):
         torch.cuda.synchronize()
 
     # untimed counting pass -> algorithmic bytes per kernel class
+    note(f"scene ready ({integ.aggregate.info.n_prims} primitives, {integ.aggregate.info.n_nodes} nodes); counting pass")
     integ.aggregate.set_counting(True)
     st_c = step()
     integ.aggregate.set_counting(False)
     st_c["spp_rendered"] = s1 - s0
     bytes_k = kernel_bytes(st_c, integ.aggregate.info, sd)
+    note("timed steps")
     for _ in range(warmup):
         step()
     barrier()
@@ -227,8 +244,9 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup):
         "metric": "path samples/s", "value": samples * world * steps / dt, "unit": "samples/s", "n_gpus": world,
         "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"C2 Cornell box path tracing: {res}x{res} @ {args.spp} spp per GPU, SimplePathIntegrator "
-                               f"max_depth {args.max_depth}, light + BSDF sampling, Gaussian filter, 4 wavelengths/sample",
+        "config": {"workload": f"{name}, SimplePathIntegrator max_depth {args.max_depth}, light + BSDF sampling, "
+                               f"Gaussian filter, 4 wavelengths/sample",
+                   "bvh_nodes": int(integ.aggregate.info.n_nodes), "bvh_build_seconds": float(integ.aggregate.info.build_seconds),
                    "samples_per_gpu": samples, "closest_rays": st["closest_rays"], "shadow_rays": st["shadow_rays"],
                    "passes": st["passes"], "merge": "none" if world == 1 else "RCCL all-reduce of the f64 film per step",
                    "bytes_per_sample": total_bytes / samples,
@@ -274,11 +292,11 @@ def main():
         out = run_trace(args, pm, torch, dist, rank, local_rank, world, args.steps, args.warmup, want_cpu)
     else:
         out, sd, integ = run_path(args, pm, torch, dist, rank, local_rank, world, args.steps, args.warmup)
-        if want_cpu and rank == 0:
+        if want_cpu and rank == 0 and args.workload == "path":
             threads = min(16, len(os.sched_getaffinity(0)))
             out["cpu_baseline"] = cpu_baseline_path(pm, sd, args.spp, args.max_depth, threads, args.cpu_seconds)
         del integ
-        if not args.no_secondary:
+        if not args.no_secondary and args.workload == "path":
             tr = run_trace(args, pm, torch, dist, rank, local_rank, world, max(3, args.steps), 1, False)
             out["closest_hit"] = {"value": tr["value"], "unit": tr["unit"], "workload": tr["config"]["workload"],
                                   "ms_per_step": tr["ms_per_step"], "roofline": tr["roofline"]}

@@ -255,6 +255,9 @@ static inline SurfInt patch_interaction(const Patch& p, const Hit& h) {     // b
     V3 pt = vlerp(vlerp(p.p00, p.p01, v), vlerp(p.p10, p.p11, v), u);
     V3 dpdu = vlerp(p.p10, p.p11, v) - vlerp(p.p00, p.p01, v);
     V3 dpdv = vlerp(p.p01, p.p11, u) - vlerp(p.p00, p.p10, u);
+    // extension shared with the product (pm_shade.hpp): a triangle is the degenerate patch (v0,v1,v2,v2); exactly on its
+    // collapsed edge dp/du is the zero vector and the reference's normal would be NaN
+    if (dpdu.x == 0.0f && dpdu.y == 0.0f && dpdu.z == 0.0f) dpdu = p.p10 - p.p00;
     V3 pabs = vabs(p.p00) + vabs(p.p10) + vabs(p.p01) + vabs(p.p11);
     V3 perr = gamma_n(6) * pabs;
     V3 n = normalized(cross(dpdu, dpdv));

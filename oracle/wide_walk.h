@@ -96,10 +96,18 @@ struct WideWalker {
     // tcull, fallback walk with immediate exact tests when the exact tests do not confirm the culling.
     bool walk(V3 ro, V3 rd, float ray_tmax, bool any_hit, uint32_t* hid, float* ht, float* hu, float* hv, Counters* ctr,
               std::vector<uint8_t>* itrace = nullptr) const {
+        {   // degenerate rays hit nothing in the reference; the kernel answers them without walking (pm_device.hpp)
+            const float dsum = std::fabs(rd.x) + std::fabs(rd.y) + std::fabs(rd.z), osum = std::fabs(ro.x) + std::fabs(ro.y) + std::fabs(ro.z);
+            if (!(dsum > 0.0f && dsum < std::numeric_limits<float>::infinity() && osum < std::numeric_limits<float>::infinity())) {
+                *hid = 0xFFFFFFFFu; *ht = ray_tmax; *hu = 0; *hv = 0;
+                return false;
+            }
+        }
         const float widen = 1.0f + 2.0f * gamma_n(3);
         const float MARGIN = 2.384185791015625e-07f;
         const uint32_t CAND_MAX = 4;
-        const float inv[3] = {1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
+        auto rcp = [](float d) { return std::fabs(d) < 1e-18f ? std::copysign(1e18f, d) : 1.0f / d; };
+        const float inv[3] = {rcp(rd.x), rcp(rd.y), rcp(rd.z)};
         const bool ng[3] = {inv[0] < 0, inv[1] < 0, inv[2] < 0};
         const uint32_t oct = (ng[0] ? 1u : 0u) | (ng[1] ? 2u : 0u) | (ng[2] ? 4u : 0u);
         const float R = maxabs(ro), D = maxabs(rd);

@@ -279,6 +279,7 @@ PMD int tri_prefilter(f3 ro, f3 rd, float R, float D, f3 v0, f3 v1, f3 v2, float
 }
 
 #define PM_CAND_MAX 4
+PMD float safe_rcp_dir(float d) { return fabsf(d) < 1e-18f ? copysignf(1e18f, d) : 1.0f / d; }
 #define PM_NODE_MARGIN 2.384185791015625e-07f   /* 4 * 2^-24: rounding of the pre-scaled slab evaluation */
 #define PM_WALK_GUARD (1u << 22)                /* per-ray bound on node steps (a corrupt buffer cannot hang a wave) */
 
@@ -373,12 +374,25 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                     const uint32_t idx = wnext + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
                     if (idx < wend && fetch(idx, &ray)) {
                         item = idx;
-                        inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+                        // A ray with a NaN / infinite / all-zero direction or a non-finite origin hits nothing in the reference
+                        // (every comparison of its primitive tests fails) but would pass every NaN-tolerant box test, i.e.
+                        // visit the whole tree: answer "miss" at once.
+                        const float dsum = fabsf(ray.d.x) + fabsf(ray.d.y) + fabsf(ray.d.z);
+                        const float osum = fabsf(ray.o.x) + fabsf(ray.o.y) + fabsf(ray.o.z);
+                        if (!(dsum > 0.0f && dsum < INFINITY && osum < INFINITY)) {
+                            HitRec miss; miss.prim_id = 0xFFFFFFFFu; miss.t = ray.tmax; miss.u = 0.0f; miss.v = 0.0f;
+                            commit(idx, false, miss);
+                        } else {
+                        // 1/d for the slab test; a (near-)zero component gets a huge FINITE reciprocal so that the pre-scaled form
+                        // q*(s/d) + (o - ro)/d stays a number (with +-inf it is inf - inf = NaN = "no constraint", and an
+                        // axis-parallel ray would visit every box of its axis-aligned column)
+                        inv = mk3(safe_rcp_dir(ray.d.x), safe_rcp_dir(ray.d.y), safe_rcp_dir(ray.d.z));
                         ngx = inv.x < 0.0f; ngy = inv.y < 0.0f; ngz = inv.z < 0.0f;
                         oct = (ngx ? 1u : 0u) | (ngy ? 2u : 0u) | (ngz ? 4u : 0u);
                         R = maxc3(abs3(ray.o)); D = maxc3(abs3(ray.d));
                         exact_mode = false;
                         start_walk();
+                        }
                     }
                 }
                 const uint32_t nw = (uint32_t)__popcll(want);
@@ -389,6 +403,11 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
         if (active) {
             // ---- one node step (the pop of an exhausted group is merged into it)
             bool ended = (ANY && (found || sure)) || ++steps > PM_WALK_GUARD;
+#ifdef PM_DEBUG_LONGWALK
+            if (steps == 20000u)
+                printf("LONGWALK any=%d o=%a %a %a d=%a %a %a tmax=%a tcull=%a sp=%d qn=%u\n", (int)ANY, ray.o.x, ray.o.y, ray.o.z,
+                       ray.d.x, ray.d.y, ray.d.z, ray.tmax, tcull, sp, qn);
+#endif
             uint32_t pm = cur.y & 0xFFu;
             if (!ended && pm == 0u) {
                 if (sp == 0) ended = true;

@@ -282,8 +282,11 @@ PMD SurfInt patch_interaction(const DShadePatch& sp, float u, float v, const flo
     const f3 p00 = mk3(sp.p[0], sp.p[1], sp.p[2]), p10 = mk3(sp.p[3], sp.p[4], sp.p[5]);
     const f3 p01 = mk3(sp.p[6], sp.p[7], sp.p[8]), p11 = mk3(sp.p[9], sp.p[10], sp.p[11]);
     const f3 pt = lerp3(lerp3(p00, p01, v), lerp3(p10, p11, v), u);
-    const f3 dpdu = lerp3(p10, p11, v) - lerp3(p00, p01, v);
+    f3 dpdu = lerp3(p10, p11, v) - lerp3(p00, p01, v);
     const f3 dpdv = lerp3(p01, p11, u) - lerp3(p00, p10, u);
+    // extension: on the collapsed edge of a degenerate patch (a triangle hit exactly at v = 1) dp/du is the zero vector and
+    // the reference's normal and shading frame become NaN; take the direction dp/du has everywhere else on the patch
+    if (dpdu.x == 0.0f && dpdu.y == 0.0f && dpdu.z == 0.0f) dpdu = p10 - p00;
     const f3 pabs = abs3(p00) + abs3(p10) + abs3(p01) + abs3(p11);
     const f3 perr = pabs * gamma_n(6);
     f3 n = norm3(cross3(dpdu, dpdv));

@@ -173,6 +173,28 @@ def shading_normal_scene(resolution=(64, 64), grid=6, spectra=None):
     return sd
 
 
+def blob_sky_scene(n_blobs=20480, resolution=(3840, 2160), seed=3, spectra=None, **blob_kw):
+    """C4: `n_blobs` x 1024 small diffuse triangles under a uniform sky (UniformInfiniteLight), camera at (0,0,-4)
+    looking down +z.  The default is the 20,971,520-triangle configuration of BASELINE.json."""
+    from . import host
+    from .aggregate import TriangleMesh
+    f32 = np.float32
+    sp = spectra or host.Spectra()
+    sd = host.SceneDescription()
+    camera_from_world = host.Transform.look_at((0.0, 0.0, -4.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+    sd.film = host.make_film(sp, resolution, filter_kind=host.PM_FILTER_GAUSSIAN, filter_radius=(1.5, 1.5), sigma=0.5)
+    sd.camera, rfw = host.make_camera(camera_from_world.inverse(), 40.0, resolution)
+    sd.render_from_world = rfw
+    pos, idx = blob_mesh(n_blobs, 1024, seed=seed, **blob_kw)
+    pos = _xf_points(rfw.m, pos)
+    sd.prims = [TriangleMesh(pos, idx)]
+    sd.materials = [host.diffuse(sp.rgb_albedo((0.7, 0.6, 0.5)))]
+    sd.prim_materials = np.zeros(len(idx), np.uint32)
+    sky, _, _ = sp.rgb_illuminant_table((0.5, 0.6, 0.8))
+    sd.lights = [host.light(host.PM_LIGHT_UNIFORM_INFINITE, sky, f32(1.0) / f32(sp.photometric(sp.d65)))]
+    return sd
+
+
 def cornell_scene(resolution=(1024, 1024), spectra=None, glass_sphere=True):
     """C2: a Cornell box built from triangles (walls, tall box, short box), lit by a PointLight just under the
     ceiling (the reference has no area light, lights/base.rs:18-22), seen through a PerspectiveCamera.

@@ -112,6 +112,22 @@ def test_patch_mesh_with_vertex_normals(pm, ora):
     assert helpers.rel_rmse(i2.image(), gi) > 5e-2
 
 
+def test_c4_shaped_scene_small(pm, ora):
+    """BASELINE.json configs[3] (blobs of triangles under a uniform sky) at a size the oracle finishes in seconds:
+    16 blobs x 1024 triangles, 96x54 @ 4 spp.  Deep tree, long-tailed walks, infinite-light NEE."""
+    res, spp = (96, 54), 4
+    sd = pm.scenes.blob_sky_scene(16, res, blob_sigma=0.25, tri_size=0.06)
+    integ, oren, params = _pair(pm, ora, sd, spp)
+    frac = _check_samples(integ, oren, params, res, spp, n=300, seed=2)
+    assert frac >= 0.99, f"only {frac:.3f} of the samples agree"
+    st = integ.render()
+    oc = oren.render(params, 8)
+    assert abs(st["closest_rays"] - oc["closest_rays"]) <= 3e-3 * oc["closest_rays"]
+    gi, oi = integ.image(), oren.image()
+    assert abs(gi.mean() - oi.mean()) <= 3e-3 * abs(oi.mean())
+    assert helpers.rel_rmse(gi, oi) <= 3e-2
+
+
 def test_random_walk_integrator(pm, ora):
     """RandomWalkIntegrator (integrators/random_walk.rs:106-173): uniform-sphere bounces, infinite lights on a miss, no
     next-event estimation.  The GPU unrolls the recursion but folds the result in the recursion's own order, so a sample

@@ -154,7 +154,15 @@ def test_edge_cases(pm, ora):
     rays["tmax"][300:320] = 0.0
     rays["tmax"][320:340] = 1e-3
     rays["o"][340:360] = pos[:20]            # origins exactly on vertices
+    # degenerate rays: NaN / zero / infinite direction, non-finite origin -> the reference's tests all fail -> miss
+    rays["d"][400:410] = np.nan
+    rays["d"][410:420, 1] = np.nan
+    rays["d"][420:430] = 0.0
+    rays["d"][430:440, 2] = np.inf
+    rays["o"][440:450, 0] = np.nan
+    rays["o"][450:460, 1] = np.inf
     ref, _ = sc.intersect(rays)
+    assert (ref["prim_id"][400:460] == 0xFFFFFFFF).all()
     _compare_closest(agg.intersect(rays), ref)
     ref_a, _ = sc.intersect_p(rays)
     assert np.array_equal(agg.intersect_p(rays), ref_a)
@@ -163,6 +171,33 @@ def test_edge_cases(pm, ora):
     r1 = pm.scenes.incoherent_rays(4096, seed=1)
     ref1, _ = sc1.intersect(r1)
     _compare_closest(one.intersect(r1), ref1)
+
+
+def test_axis_parallel_rays(pm, ora):
+    """exactly-zero direction components (sample_uniform_sphere returns (0,0,1) for u.x = 0): same hits as the reference,
+    and the walk must not degrade into visiting every box of the ray's axis-aligned column."""
+    pos, idx = pm.scenes.blob_mesh(64, 1024, seed=3)
+    agg, sc = _build_both(pm, ora, [("tri", pos, idx)])
+    rng = np.random.default_rng(1)
+    n = 30000
+    rays = np.zeros(n, pm.RAY_DTYPE)
+    rays["o"] = rng.uniform(-1.2, 1.2, (n, 3))
+    rays["tmax"] = np.inf
+    axes = rng.integers(0, 3, n)
+    rays["d"][np.arange(n), axes] = rng.choice([-1.0, 1.0], n) * rng.uniform(0.5, 5, n)
+    rays["d"][n // 2:, (axes[n // 2:] + 1) % 3] = rng.uniform(-1, 1, n - n // 2)
+    rays["d"][:50] *= -0.0 + 1.0          # keep a few with negative zeros
+    rays["d"][:50][rays["d"][:50] == 0] = -0.0
+    ref, _ = sc.intersect(rays)
+    assert (ref["prim_id"] != 0xFFFFFFFF).sum() > 1000
+    agg.set_counting(True)
+    agg.reset_counters()
+    _compare_closest(agg.intersect(rays), ref)
+    c = agg.counters()
+    agg.set_counting(False)
+    assert c["nodes_visited"] / n < 40, c
+    ref_a, _ = sc.intersect_p(rays)
+    assert np.array_equal(agg.intersect_p(rays), ref_a)
 
 
 def test_device_pointers_in_place(pm, ora):
