@@ -200,6 +200,49 @@ def test_axis_parallel_rays(pm, ora):
     assert np.array_equal(agg.intersect_p(rays), ref_a)
 
 
+def test_c3_full_size(pm, ora):
+    """BASELINE.json configs[2] at full geometry size (1,048,576 triangles): 2^21 primary + 2^20 incoherent + shadow rays.
+    * against the CPU walk of the same GPU-layout tree: bit-identical hits INCLUDING ties (same order of exact tests);
+    * against the reference traversal (its own binary tree) on a 2^17-ray subsample: bit-identical t/u/v, ids up to ties;
+    * size-independent properties: any-hit with tmax just beyond / just before the closest t agrees with the closest hit."""
+    pos, idx = pm.scenes.blob_mesh(1024, 1024, seed=1)
+    agg = pm.GpuAggregate([pm.TriangleMesh(pos, idx)])
+    prim = pm.scenes.primary_rays(2048, 1024)
+    inc = pm.scenes.incoherent_rays(1 << 20, seed=2)
+    hp = agg.intersect(prim)
+    sh = pm.scenes.shadow_rays(prim, hp)
+    rays = np.concatenate([prim, inc, sh[: 1 << 20]])
+    gpu = agg.intersect(rays)
+    nb, pb = agg.node_buffer(), agg.prim_buffer()
+    cpu, _ = ora.wide_trace(nb, pb, rays, nthreads=16)
+    assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32))
+    occ = agg.intersect_p(rays)
+    occ_cpu, _ = ora.wide_trace(nb, pb, rays, any_hit=True, nthreads=16)
+    assert np.array_equal(occ, occ_cpu)
+    assert np.array_equal(occ.astype(bool), gpu["prim_id"] != pm.PM_MISS)
+    # reference traversal on a subsample
+    sel = np.random.default_rng(0).choice(len(rays), 1 << 17, replace=False)
+    sc = ora.Scene()
+    sc.add_triangle_mesh(pos, idx)
+    sc.build(ora.SPLIT_MIDDLE, 255)
+    ref, _ = sc.intersect(np.ascontiguousarray(rays[sel]), nthreads=16)
+    g = gpu[sel]
+    for f in ("t", "u", "v"):
+        same = g[f].view(np.uint32) == ref[f].view(np.uint32)
+        assert same.sum() >= len(sel) - 2, f          # (u, v) may differ where an exact-t tie picked the other primitive
+    assert (g["prim_id"] != ref["prim_id"]).sum() <= 2
+    # any-hit vs closest-hit consistency
+    hit = gpu["prim_id"] != pm.PM_MISS
+    r2 = rays[hit].copy()
+    r2["tmax"] = gpu["t"][hit] * np.float32(1 + 1e-5)
+    assert agg.intersect_p(r2).all()
+    r3 = rays[hit].copy()
+    r3["tmax"] = gpu["t"][hit] * np.float32(1 - 1e-5)
+    again = agg.intersect(r3)
+    assert ((again["prim_id"] == pm.PM_MISS) | (again["t"] < gpu["t"][hit])).all()
+    assert (again["prim_id"] == pm.PM_MISS).mean() > 0.99
+
+
 def test_device_pointers_in_place(pm, ora):
     """rays/hits already resident in HBM (torch tensors) are used without a copy."""
     import torch
