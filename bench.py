@@ -32,6 +32,23 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 KERNEL_NAMES = ["raygen_kernel", "closest_kernel", "shade_kernel", "shadow_kernel", "accumulate_kernel"]
 
 
+def pmc_traffic(kernel_prefix, tag):
+    """HBM bytes per launch of `kernel_prefix` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/rNN/pmc_summary_<tag>.json, made by scripts/profile_gpu.sh + scripts/summarize_pmc.py): FETCH_SIZE doubled
+    for wide loads as MI355X_MICROARCH.md prescribes, plus WRITE_SIZE.  None when no summary is committed."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_summary_{tag}.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        for name, v in d.items():
+            if name.startswith(kernel_prefix) and "true" not in name.split("<")[-1] and "fetch_bytes_x2_wide_loads" in v \
+                    and "write_bytes" in v:
+                return (v["fetch_bytes_x2_wide_loads"] + v["write_bytes"]) / max(1, v["dispatches"]), os.path.relpath(path, ROOT)
+    return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,7 +163,8 @@ def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, wan
                    "rays_per_gpu": n_rays, "hit_fraction": hit_frac, "bvh_nodes": int(agg.info.n_nodes),
                    "bvh_node_bytes": int(s_node), "tri_record_bytes": int(s_prim)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("trace_kernel<false, false>", "trace")[0],
+                     "traffic_source": pmc_traffic("trace_kernel<false, false>", "trace")[1],
                      "kernel": "trace_kernel<false,false>", "kernel_ms": k_ms,
                      "bytes_per_ray": bytes_per_ray, "nodes_per_ray": n_node, "prims_per_ray": n_prim},
     }
@@ -260,7 +278,10 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup):
                    "kernel_GBps": dict(zip(KERNEL_NAMES, [float(b / (m * 1e-3) / 1e9) if m > 0 else 0.0
                                                           for b, m in zip(bytes_k, ms_k)]))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": KERNEL_NAMES[dom],
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic(KERNEL_NAMES[dom], "path")[0] if args.workload == "path" else None,
+                     "traffic_source": pmc_traffic(KERNEL_NAMES[dom], "path")[1] if args.workload == "path" else None,
+                     "kernel": KERNEL_NAMES[dom],
                      "kernel_ms": float(ms_k[dom] / max(1.0, launches[dom])), "launches_per_step": float(launches[dom]),
                      "bytes_per_launch": bytes_k[dom] / max(1.0, launches[dom]),
                      "whole_render": {"achieved": total_bytes / (float(ms_k.sum()) * 1e-3) / 1e9,

@@ -57,9 +57,10 @@ __global__ __launch_bounds__(RB) void raygen_kernel(RenderConst rc, SceneArrays 
     const bool inside = slot_pixel(rc, slot, &px, &py, &s);
     pa.q0[slot] = slot;     // queue 0 is the identity; padded slots are retired by the first shade pass
     if (slot == 0) pa.counts[0] = npaths;
-    if (!inside) {
+    if (!inside) {      // padded slot of a ragged window: dead (ray_o.w != 0 tells the closest-hit fetch without a misc load)
         pa.misc[slot] = make_uint2(0xFFFFFFFFu, 0u);
         pa.L[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pa.ray_o[slot] = make_float4(0.f, 0.f, 0.f, 1.f);
         return;
     }
     Rng rng = rng_start(px, py, rc.seed, (unsigned long long)s, 0ull);
@@ -101,8 +102,9 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR void closest_kernel(SceneArrays sc
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
         const uint32_t slot = queue[i];
-        if (pa.misc[slot].x == 0xFFFFFFFFu) return false;
-        const float4 o = pa.ray_o[slot], d = pa.ray_d[slot];
+        const float4 o = pa.ray_o[slot];
+        if (o.w != 0.0f) return false;          // dead slot (raygen)
+        const float4 d = pa.ray_d[slot];
         ray->o = mk3(o.x, o.y, o.z); ray->d = mk3(d.x, d.y, d.z); ray->tmax = INFINITY;
         return true;
     };
