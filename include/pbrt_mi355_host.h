@@ -47,6 +47,10 @@ int pmh_rgb_to_coeffs(const float* rgb3, const float* cie_x471, const float* cie
 int pmh_srgb_matrices(const float* cie_x471, const float* cie_y471, const float* cie_z471, const float* illuminant471,
                       float* xyz_from_rgb9, float* rgb_from_xyz9);
 
+/* Image::write_exr (imaging/image.rs:48-57): width x height RGB f32 pixels (row-major, 3 floats per pixel) as a
+ * single-part scanline OpenEXR file with FLOAT channels B, G, R, no compression.  Returns non-zero on I/O failure. */
+int pmh_write_exr(const char* path, int width, int height, const float* rgb);
+
 #ifdef __cplusplus
 }
 #endif

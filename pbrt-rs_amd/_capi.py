@@ -134,6 +134,7 @@ SYMBOLS = {
     "pmh_sigmoid_poly": (C.c_float, [_P, C.c_float]),
     "pmh_rgb_to_coeffs": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "pmh_srgb_matrices": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "pmh_write_exr": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _P]),
 }
 
 

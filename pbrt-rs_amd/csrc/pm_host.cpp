@@ -6,7 +6,9 @@
 #include "../../include/pbrt_mi355_host.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 
 namespace {
@@ -368,6 +370,69 @@ int pmh_srgb_matrices(const float* cie_x, const float* cie_y, const float* cie_z
                     (xr[3] * xr[7] - xr[4] * xr[6]) * i2, (xr[1] * xr[6] - xr[0] * xr[7]) * i2, (xr[0] * xr[4] - xr[1] * xr[3]) * i2};
     for (int k = 0; k < 9; ++k) { xyz_from_rgb9[k] = (float)xr[k]; rgb_from_xyz9[k] = (float)rx[k]; }
     return 0;
+}
+
+// ---- Image::write_exr (imaging/image.rs:48-57): minimal OpenEXR 2.0 scanline writer, FLOAT channels, no compression
+int pmh_write_exr(const char* path, int width, int height, const float* rgb) {
+    if (!path || !rgb || width <= 0 || height <= 0) return 1;
+    std::string hdr;
+    auto put = [&](const void* p, size_t n) { hdr.append(reinterpret_cast<const char*>(p), n); };
+    auto put_i32 = [&](int32_t v) { put(&v, 4); };
+    auto put_str = [&](const char* z) { hdr.append(z); hdr.push_back('\0'); };
+    auto attr = [&](const char* name, const char* type, const std::string& value) {
+        put_str(name); put_str(type); put_i32((int32_t)value.size()); hdr.append(value);
+    };
+    const unsigned char magic[8] = {0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0};
+    put(magic, 8);
+    {   // chlist: channels in alphabetical order
+        std::string v;
+        for (const char* ch : {"B", "G", "R"}) {
+            v.append(ch); v.push_back('\0');
+            const int32_t type = 2;   // FLOAT
+            v.append(reinterpret_cast<const char*>(&type), 4);
+            const unsigned char lin[4] = {0, 0, 0, 0};
+            v.append(reinterpret_cast<const char*>(lin), 4);
+            const int32_t one = 1;
+            v.append(reinterpret_cast<const char*>(&one), 4); v.append(reinterpret_cast<const char*>(&one), 4);
+        }
+        v.push_back('\0');
+        attr("channels", "chlist", v);
+    }
+    attr("compression", "compression", std::string(1, '\0'));
+    {
+        const int32_t box[4] = {0, 0, width - 1, height - 1};
+        std::string v(reinterpret_cast<const char*>(box), 16);
+        attr("dataWindow", "box2i", v);
+        attr("displayWindow", "box2i", v);
+    }
+    attr("lineOrder", "lineOrder", std::string(1, '\0'));
+    { const float one = 1.0f; attr("pixelAspectRatio", "float", std::string(reinterpret_cast<const char*>(&one), 4)); }
+    { const float z[2] = {0.0f, 0.0f}; attr("screenWindowCenter", "v2f", std::string(reinterpret_cast<const char*>(z), 8)); }
+    { const float one = 1.0f; attr("screenWindowWidth", "float", std::string(reinterpret_cast<const char*>(&one), 4)); }
+    hdr.push_back('\0');
+    const uint64_t line_bytes = 8ull + 3ull * 4ull * (uint64_t)width;
+    const uint64_t table_pos = hdr.size();
+    std::FILE* f = std::fopen(path, "wb");
+    if (!f) return 2;
+    bool ok = std::fwrite(hdr.data(), 1, hdr.size(), f) == hdr.size();
+    for (int y = 0; y < height && ok; ++y) {
+        const uint64_t off = table_pos + 8ull * (uint64_t)height + (uint64_t)y * line_bytes;
+        ok = std::fwrite(&off, 8, 1, f) == 1;
+    }
+    std::vector<float> line(3 * (size_t)width);
+    for (int y = 0; y < height && ok; ++y) {
+        const float* row = rgb + 3 * (size_t)y * width;
+        for (int x = 0; x < width; ++x) {
+            line[x] = row[3 * x + 2];                          // B
+            line[(size_t)width + x] = row[3 * x + 1];          // G
+            line[2 * (size_t)width + x] = row[3 * x];          // R
+        }
+        const int32_t yy = y, sz = (int32_t)(3 * 4 * width);
+        ok = std::fwrite(&yy, 4, 1, f) == 1 && std::fwrite(&sz, 4, 1, f) == 1 &&
+             std::fwrite(line.data(), 4, line.size(), f) == line.size();
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? 0 : 3;
 }
 
 }  // extern "C"

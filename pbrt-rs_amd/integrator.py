@@ -77,6 +77,12 @@ class WavefrontIntegrator:
         self.aggregate._check(self._lib.pm_film_image(self._h, out.ctypes.data))
         return out
 
+    def write_exr(self, path):
+        """RGBFilm::write_image -> Image::write_exr (camera/film.rs:255-259, imaging/image.rs:48-57)"""
+        img = np.ascontiguousarray(self.image(), dtype=np.float32)
+        if self._lib.pmh_write_exr(str(path).encode(), self.width, self.height, img.ctypes.data) != 0:
+            raise OSError(f"could not write {path}")
+
     def stats(self):
         s = PmRenderStats()
         self.aggregate._check(self._lib.pm_get_render_stats(self._h, C.byref(s)))

@@ -22,3 +22,13 @@ assert x.size == y.size == z.size == lam.size == 471 and d65.size == 214, (x.siz
 assert lam[0] == 360 and lam[-1] == 830
 np.savez(sys.argv[1], cie_x=x, cie_y=y, cie_z=z, cie_lambda=lam, d65_interleaved=d65)
 print("ok", x[:3], d65[:6])
+
+# the same numbers as raw little-endian float32 for the C++ host mirror (include/pbrt_mi355.hpp Spectra):
+# "PMCIE1\0\0", cie_x[471], cie_y[471], cie_z[471], uint32 n, d65_interleaved[n]
+import struct
+with open(sys.argv[1].replace(".npz", ".bin"), "wb") as f:
+    f.write(b"PMCIE1\0\0")
+    for a in (x, y, z):
+        f.write(a.astype(np.float32).tobytes())
+    f.write(struct.pack("<I", d65.size))
+    f.write(d65.astype(np.float32).tobytes())

@@ -157,3 +157,48 @@ def test_shard_maths(pm):
             assert w[0][1] == bounds[1] and w[-1][3] == bounds[3]
             assert all(w[k][3] == w[k + 1][1] for k in range(world - 1))
             assert all(a[0] == bounds[0] and a[2] == bounds[2] for a in w)
+
+
+def _read_exr(path):
+    """minimal reader for single-part scanline uncompressed FLOAT EXR files (what pmh_write_exr writes)"""
+    import struct
+    b = open(path, "rb").read()
+    assert b[:4] == bytes([0x76, 0x2F, 0x31, 0x01]) and b[4] == 2 and b[5:8] == b"\x00\x00\x00"
+    pos, attrs = 8, {}
+    while b[pos] != 0:
+        e = b.index(b"\x00", pos); name = b[pos:e].decode(); pos = e + 1
+        e = b.index(b"\x00", pos); typ = b[pos:e].decode(); pos = e + 1
+        (size,) = struct.unpack_from("<i", b, pos); pos += 4
+        attrs[name] = (typ, b[pos:pos + size]); pos += size
+    pos += 1
+    assert attrs["compression"][1] == b"\x00" and attrs["lineOrder"][1] == b"\x00"
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    ch, p = [], 0
+    cl = attrs["channels"][1]
+    while cl[p] != 0:
+        e = cl.index(b"\x00", p); ch.append(cl[p:e].decode()); p = e + 1
+        assert struct.unpack_from("<i", cl, p)[0] == 2      # FLOAT
+        p += 16
+    assert ch == ["B", "G", "R"]
+    offs = struct.unpack_from(f"<{h}Q", b, pos)
+    img = np.zeros((h, w, 3), np.float32)
+    for y in range(h):
+        yy, size = struct.unpack_from("<2i", b, offs[y])
+        assert yy == y and size == 12 * w
+        line = np.frombuffer(b, np.float32, 3 * w, offs[y] + 8).reshape(3, w)
+        img[y, :, 2], img[y, :, 1], img[y, :, 0] = line[0], line[1], line[2]
+    assert offs[-1] + 8 + 12 * w == len(b)
+    return img
+
+
+def test_exr_writer_round_trip(pm, tmp_path):
+    """Image::write_exr counterpart (imaging/image.rs:48-57): what is written parses back bit for bit"""
+    rng = np.random.default_rng(0)
+    img = rng.normal(size=(7, 13, 3)).astype(np.float32)
+    img[0, 0] = [np.inf, 0.0, -0.0]
+    path = tmp_path / "t.exr"
+    assert pm._capi.lib().pmh_write_exr(str(path).encode(), 13, 7, img.ctypes.data) == 0
+    back = _read_exr(path)
+    assert np.array_equal(back.view(np.uint32), img.view(np.uint32))
+    assert pm._capi.lib().pmh_write_exr(str(tmp_path / "no" / "dir.exr").encode(), 13, 7, img.ctypes.data) != 0
