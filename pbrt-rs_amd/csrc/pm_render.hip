@@ -35,10 +35,6 @@ struct SceneArrays {
     const float* pool;
 };
 
-__device__ __forceinline__ uint32_t xcd_remap_r(uint32_t b, uint32_t nb) {
-    const uint32_t q = nb >> 3, r = nb & 7u, x = b & 7u;
-    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (b >> 3);
-}
 __device__ __forceinline__ bool slot_pixel(const RenderConst& rc, uint32_t slot, int* px, int* py, int* s) {
     const uint32_t p = slot % (uint32_t)rc.npix_pad;
     *s = rc.s_base + (int)(slot / (uint32_t)rc.npix_pad);

@@ -182,6 +182,28 @@ def test_window_and_sample_split_are_bit_identical(pm, ora):
     np.testing.assert_allclose(integ.film(), whole, rtol=1e-14, atol=0)
 
 
+def test_film_exchange_through_device_pointers(pm):
+    """the multi-GPU merge path of bench.py: film read into / added from buffers that live in HBM (torch tensors)"""
+    import torch
+    res, spp = (40, 24), 8
+    sd = pm.scenes.main_rs_scene(res)
+    integ = pm.WavefrontIntegrator(5, True, True, sd, spp)
+    integ.render()
+    whole = integ.film().copy()
+    d = torch.empty((res[1], res[0], 4), dtype=torch.float64, device="cuda")
+    integ.film(out=d)
+    assert np.array_equal(d.cpu().numpy().view(np.uint64), whole.view(np.uint64))
+    integ.clear()
+    integ.render(samples=(0, 4))
+    integ.film(out=d)
+    integ.clear()
+    integ.render(samples=(4, 8))
+    integ.film_add(d)
+    np.testing.assert_allclose(integ.film(), whole, rtol=1e-14, atol=0)
+    stats = pm.distributed.render_distributed(integ)           # world size 1: plain render through the same entry point
+    assert np.array_equal(stats.cpu().numpy().view(np.uint64), whole.view(np.uint64))
+
+
 def test_render_errors(pm):
     sd = pm.scenes.main_rs_scene((16, 16))
     integ = pm.WavefrontIntegrator(5, True, True, sd, 4)
