@@ -43,6 +43,13 @@ float pmh_sigmoid_poly(const float* c3, float lambda);   /* color/color_space.rs
  * problem for one RGB (color/color_space.rs:110-184, util/data.rs:1684-1702) */
 int pmh_rgb_to_coeffs(const float* rgb3, const float* cie_x471, const float* cie_y471, const float* cie_z471,
                       const float* illuminant471, const float* xyz_from_rgb9, float* out_c3);
+/* The RGBToSpectrumTable the reference loads from src/util/rgbspectrum_srgb.txt (util/data.rs:1684-1702; the file is
+ * missing upstream), regenerated: z_nodes64[64] and coeffs[3*64*64*64*3] in CoefficientTable's layout
+ * (color/color_space.rs:200-212).  About 786k small optimisations: seconds on a few threads. */
+int pmh_rgb_table_generate(const float* cie_x471, const float* cie_y471, const float* cie_z471, const float* illuminant471,
+                           const float* xyz_from_rgb9, float* z_nodes64, float* coeffs, int nthreads);
+/* RGBToSpectrumTable::convert (color/color_space.rs:128-185): trilinear lookup, f32, the reference's operation order */
+void pmh_rgb_table_lookup(const float* z_nodes64, const float* coeffs, const float* rgb3, float* out_c3);
 /* RGBColorSpace::new for the sRGB primaries (color/color_space.rs:40-89) */
 int pmh_srgb_matrices(const float* cie_x471, const float* cie_y471, const float* cie_z471, const float* illuminant471,
                       float* xyz_from_rgb9, float* rgb_from_xyz9);

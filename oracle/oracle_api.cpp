@@ -304,6 +304,28 @@ void ora_to_sensor_rgb(const float* sensor_bar3x471, float imaging_ratio, const 
 float ora_dense_at(const float* table471, float lambda) { return dense_at(table471, lambda); }
 float ora_sigmoid_poly(float c0, float c1, float c2, float lambda) { return sigmoid_poly(c0, c1, c2, lambda); }
 
+// RGBToSpectrumTable::convert (color/color_space.rs:128-185) restated for the golden test of the regenerated table
+void ora_rgb_table_convert(const float* z_nodes, const float* coeffs, const float* rgb_in, float* out3) {
+    const int R = 64;
+    float rgb[3];
+    for (int i = 0; i < 3; ++i) rgb[i] = rgb_in[i] < 0.0f ? 0.0f : rgb_in[i];      // RGB::clamp_zero
+    if (rgb[0] == rgb[1] && rgb[1] == rgb[2]) { out3[0] = 0; out3[1] = 0; out3[2] = (rgb[0] - 0.5f) / std::sqrt(rgb[0] * (1.0f - rgb[0])); return; }
+    int max_i = rgb[0] > rgb[1] ? (rgb[0] > rgb[2] ? 0 : 2) : (rgb[1] > rgb[2] ? 1 : 2);
+    float z = rgb[max_i];
+    float x = rgb[(max_i + 1) % 3] * (float)(R - 1) / z, y = rgb[(max_i + 2) % 3] * (float)(R - 1) / z;
+    int xi = std::min((int)x, R - 2), yi = std::min((int)y, R - 2);
+    std::vector<float> zn(z_nodes, z_nodes + R);
+    int left = 0, right = R - 1;
+    while (left < right) { int mid = left + (right - left) / 2; if (zn[mid] < z) left = mid + 1; else right = mid; }
+    int zi = left == 0 ? 0 : (left >= R - 1 ? R - 2 : left - 1);
+    float dx = x - (float)xi, dy = y - (float)yi, dz = (z - zn[zi]) / (zn[zi + 1] - zn[zi]);
+    for (int c = 0; c < 3; ++c) {
+        auto co = [&](int a, int b, int d) { return coeffs[3 * ((((size_t)max_i * R + zi + d) * R + yi + b) * R + xi + a) + c]; };
+        out3[c] = lerpf(lerpf(lerpf(co(0, 0, 0), co(1, 0, 0), dx), lerpf(co(0, 1, 0), co(1, 1, 0), dx), dy),
+                        lerpf(lerpf(co(0, 0, 1), co(1, 0, 1), dx), lerpf(co(0, 1, 1), co(1, 1, 1), dx), dy), dz);
+    }
+}
+
 // ---- single-function probes used by the golden-vector tests -----------------------------------
 float ora_next_float_up(float v) { return next_float_up(v); }
 float ora_next_float_down(float v) { return next_float_down(v); }

@@ -135,6 +135,8 @@ SYMBOLS = {
     "pmh_rgb_to_coeffs": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "pmh_srgb_matrices": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "pmh_write_exr": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _P]),
+    "pmh_rgb_table_generate": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int]),
+    "pmh_rgb_table_lookup": (None, [_P, _P, _P, _P]),
 }
 
 

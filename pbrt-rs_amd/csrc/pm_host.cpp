@@ -5,10 +5,13 @@
 // can build the same scenes without a Rust toolchain.  f32 arithmetic in the reference's operation order.
 #include "../../include/pbrt_mi355_host.h"
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -248,48 +251,52 @@ float pmh_sigmoid_poly(const float* c3, float lambda) { return sigmoid_poly(c3, 
 // problem the table generator solves (Jakob & Hanika 2019: Gauss-Newton on the CIELAB residual of the spectrum
 // sigmoid(c0 l^2 + c1 l + c2) under the colour space's illuminant) directly for one RGB.  Not bit-identical to a
 // table lookup (no interpolation error here); see DESIGN.md.
-int pmh_rgb_to_coeffs(const float* rgb3, const float* cie_x, const float* cie_y, const float* cie_z,
-                      const float* illuminant471, const float* xyz_from_rgb9, float* out_c3) {
-    double r = rgb3[0], g = rgb3[1], b = rgb3[2];
-    if (r == g && g == b) {   // color_space.rs:130-136
-        float x = rgb3[0];
-        out_c3[0] = 0.0f; out_c3[1] = 0.0f; out_c3[2] = (x - 0.5f) / std::sqrt(x * (1.0f - x));
-        return 0;
+namespace {
+// Gauss-Newton solver of Jakob & Hanika's RGB -> sigmoid-polynomial fit (CIELAB residual under the colour space's
+// illuminant), in the normalised wavelength domain [0,1]; `co` is both the warm start and the result.
+struct RgbSolver {
+    static constexpr int N = 471;
+    std::vector<double> tbl, lam;
+    double wp[3] = {0, 0, 0};
+    float xyz_from_rgb[9];
+    bool ok = false;
+    RgbSolver(const float* cie_x, const float* cie_y, const float* cie_z, const float* illuminant471, const float* xyz_from_rgb9)
+        : tbl(3 * N), lam(N) {
+        std::memcpy(xyz_from_rgb, xyz_from_rgb9, sizeof(xyz_from_rgb));
+        double rgb_from_xyz[9];
+        {   // 3x3 inverse
+            const float* m = xyz_from_rgb9;
+            double a = m[0], bb = m[1], c = m[2], d = m[3], e = m[4], f = m[5], gg = m[6], h = m[7], i = m[8];
+            double det = a * (e * i - f * h) - bb * (d * i - f * gg) + c * (d * h - e * gg);
+            if (det == 0) return;
+            double id = 1.0 / det;
+            double inv[9] = {(e * i - f * h) * id, (c * h - bb * i) * id, (bb * f - c * e) * id, (f * gg - d * i) * id, (a * i - c * gg) * id,
+                             (c * d - a * f) * id, (d * h - e * gg) * id, (bb * gg - a * h) * id, (a * e - bb * d) * id};
+            std::memcpy(rgb_from_xyz, inv, sizeof(inv));
+        }
+        // quadrature tables: tbl[c][i] = weight_i * I(l_i) * (rgb_from_xyz * xyz(l_i))[c], normalised so white -> (1,1,1)
+        double ynorm = 0;
+        for (int i = 0; i < N; ++i) {
+            double w = (i == 0 || i == N - 1) ? 0.5 : 1.0;   // trapezoid, 1 nm
+            double I = illuminant471[i];
+            double xyz[3] = {cie_x[i] * I * w, cie_y[i] * I * w, cie_z[i] * I * w};
+            ynorm += xyz[1];
+            for (int c = 0; c < 3; ++c) wp[c] += xyz[c];
+            for (int c = 0; c < 3; ++c) tbl[c * N + i] = rgb_from_xyz[c * 3 + 0] * xyz[0] + rgb_from_xyz[c * 3 + 1] * xyz[1] + rgb_from_xyz[c * 3 + 2] * xyz[2];
+            lam[i] = (double)i / (N - 1);
+        }
+        for (auto& v : tbl) v /= ynorm;
+        for (int c = 0; c < 3; ++c) wp[c] /= ynorm;
+        ok = true;
     }
-    const int N = 471;
-    double rgb_from_xyz[9];
-    {   // 3x3 inverse
-        const float* m = xyz_from_rgb9;
-        double a = m[0], bb = m[1], c = m[2], d = m[3], e = m[4], f = m[5], gg = m[6], h = m[7], i = m[8];
-        double det = a * (e * i - f * h) - bb * (d * i - f * gg) + c * (d * h - e * gg);
-        if (det == 0) return 1;
-        double id = 1.0 / det;
-        double inv[9] = {(e * i - f * h) * id, (c * h - bb * i) * id, (bb * f - c * e) * id, (f * gg - d * i) * id, (a * i - c * gg) * id,
-                         (c * d - a * f) * id, (d * h - e * gg) * id, (bb * gg - a * h) * id, (a * e - bb * d) * id};
-        std::memcpy(rgb_from_xyz, inv, sizeof(inv));
-    }
-    // quadrature tables: rgb_tbl[c][i] = weight_i * I(l_i) * (rgb_from_xyz * xyz(l_i))[c], normalised so white -> (1,1,1)
-    std::vector<double> tbl(3 * N), lam(N);
-    double wp[3] = {0, 0, 0}, ynorm = 0;
-    for (int i = 0; i < N; ++i) {
-        double w = (i == 0 || i == N - 1) ? 0.5 : 1.0;   // trapezoid, 1 nm
-        double I = illuminant471[i];
-        double xyz[3] = {cie_x[i] * I * w, cie_y[i] * I * w, cie_z[i] * I * w};
-        ynorm += xyz[1];
-        for (int c = 0; c < 3; ++c) wp[c] += xyz[c];
-        for (int c = 0; c < 3; ++c) tbl[c * N + i] = rgb_from_xyz[c * 3 + 0] * xyz[0] + rgb_from_xyz[c * 3 + 1] * xyz[1] + rgb_from_xyz[c * 3 + 2] * xyz[2];
-        lam[i] = (double)i / (N - 1);
-    }
-    for (auto& v : tbl) v /= ynorm;
-    for (int c = 0; c < 3; ++c) wp[c] /= ynorm;
-    auto lab = [&](const double* rgbv, double* out) {
+    void lab(const double* rgbv, double* out) const {
         double xyz[3];
-        for (int k = 0; k < 3; ++k) xyz[k] = xyz_from_rgb9[k * 3] * rgbv[0] + xyz_from_rgb9[k * 3 + 1] * rgbv[1] + xyz_from_rgb9[k * 3 + 2] * rgbv[2];
+        for (int k = 0; k < 3; ++k) xyz[k] = xyz_from_rgb[k * 3] * rgbv[0] + xyz_from_rgb[k * 3 + 1] * rgbv[1] + xyz_from_rgb[k * 3 + 2] * rgbv[2];
         auto f = [](double t) { const double d = 6.0 / 29.0; return t > d * d * d ? std::cbrt(t) : t / (3 * d * d) + 4.0 / 29.0; };
         double fx = f(xyz[0] / wp[0]), fy = f(xyz[1] / wp[1]), fz = f(xyz[2] / wp[2]);
         out[0] = 116 * fy - 16; out[1] = 500 * (fx - fy); out[2] = 200 * (fy - fz);
-    };
-    auto residual = [&](const double* co, double* res) {
+    }
+    void residual(const double* target, const double* co, double* res) const {
         double out[3] = {0, 0, 0};
         for (int i = 0; i < N; ++i) {
             double x = (co[0] * lam[i] + co[1]) * lam[i] + co[2];
@@ -297,46 +304,138 @@ int pmh_rgb_to_coeffs(const float* rgb3, const float* cie_x, const float* cie_y,
             for (int c = 0; c < 3; ++c) out[c] += tbl[c * N + i] * s;
         }
         double l0[3], l1[3];
-        const double target[3] = {r, g, b};
         lab(target, l0); lab(out, l1);
         for (int c = 0; c < 3; ++c) res[c] = l0[c] - l1[c];
-    };
-    double co[3] = {0, 0, 0};
-    for (int it = 0; it < 30; ++it) {
-        double res[3]; residual(co, res);
-        double J[3][3];
-        for (int k = 0; k < 3; ++k) {
-            double t[3] = {co[0], co[1], co[2]}, r0[3], r1[3];
-            const double eps = 1e-4;
-            t[k] = co[k] - eps; residual(t, r0);
-            t[k] = co[k] + eps; residual(t, r1);
-            for (int j = 0; j < 3; ++j) J[j][k] = (r1[j] - r0[j]) / (2 * eps);
+    }
+    void solve(const double* target, double* co) const {
+        for (int it = 0; it < 30; ++it) {
+            double res[3]; residual(target, co, res);
+            double J[3][3];
+            for (int k = 0; k < 3; ++k) {
+                double t[3] = {co[0], co[1], co[2]}, r0[3], r1[3];
+                const double eps = 1e-4;
+                t[k] = co[k] - eps; residual(target, t, r0);
+                t[k] = co[k] + eps; residual(target, t, r1);
+                for (int j = 0; j < 3; ++j) J[j][k] = (r1[j] - r0[j]) / (2 * eps);
+            }
+            // solve J x = res (Cramer)
+            double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                         J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+            if (std::fabs(det) < 1e-30) break;
+            double x[3];
+            for (int k = 0; k < 3; ++k) {
+                double M[3][3];
+                std::memcpy(M, J, sizeof(M));
+                for (int j = 0; j < 3; ++j) M[j][k] = res[j];
+                x[k] = (M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                        M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0])) / det;
+            }
+            double rr = 0;
+            for (int k = 0; k < 3; ++k) { co[k] -= x[k]; rr += res[k] * res[k]; }
+            double mx = std::fmax(std::fmax(std::fabs(co[0]), std::fabs(co[1])), std::fabs(co[2]));
+            if (mx > 200) for (int k = 0; k < 3; ++k) co[k] *= 200 / mx;
+            if (rr < 1e-12) break;
         }
-        // solve J x = res (Cramer)
-        double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
-                     J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
-        if (std::fabs(det) < 1e-30) break;
-        double x[3];
-        for (int k = 0; k < 3; ++k) {
-            double M[3][3];
-            std::memcpy(M, J, sizeof(M));
-            for (int j = 0; j < 3; ++j) M[j][k] = res[j];
-            x[k] = (M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
-                    M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0])) / det;
-        }
-        double rr = 0;
-        for (int k = 0; k < 3; ++k) { co[k] -= x[k]; rr += res[k] * res[k]; }
-        double mx = std::fmax(std::fmax(std::fabs(co[0]), std::fabs(co[1])), std::fabs(co[2]));
-        if (mx > 200) for (int k = 0; k < 3; ++k) co[k] *= 200 / mx;
-        if (rr < 1e-12) break;
     }
     // from the normalised wavelength domain to nanometres
-    const double c0 = 360.0, c1 = 1.0 / (830.0 - 360.0);
-    double A = co[0], B = co[1], C = co[2];
-    out_c3[0] = (float)(A * c1 * c1);
-    out_c3[1] = (float)(B * c1 - 2 * A * c0 * c1 * c1);
-    out_c3[2] = (float)(C - B * c0 * c1 + A * (c0 * c1) * (c0 * c1));
+    static void to_nm(const double* co, float* out_c3) {
+        const double c0 = 360.0, c1 = 1.0 / (830.0 - 360.0);
+        double A = co[0], B = co[1], C = co[2];
+        out_c3[0] = (float)(A * c1 * c1);
+        out_c3[1] = (float)(B * c1 - 2 * A * c0 * c1 * c1);
+        out_c3[2] = (float)(C - B * c0 * c1 + A * (c0 * c1) * (c0 * c1));
+    }
+};
+}  // namespace
+
+int pmh_rgb_to_coeffs(const float* rgb3, const float* cie_x, const float* cie_y, const float* cie_z,
+                      const float* illuminant471, const float* xyz_from_rgb9, float* out_c3) {
+    if (rgb3[0] == rgb3[1] && rgb3[1] == rgb3[2]) {   // color_space.rs:130-136
+        float x = rgb3[0];
+        out_c3[0] = 0.0f; out_c3[1] = 0.0f; out_c3[2] = (x - 0.5f) / std::sqrt(x * (1.0f - x));
+        return 0;
+    }
+    RgbSolver sv(cie_x, cie_y, cie_z, illuminant471, xyz_from_rgb9);
+    if (!sv.ok) return 1;
+    const double target[3] = {rgb3[0], rgb3[1], rgb3[2]};
+    double co[3] = {0, 0, 0};
+    sv.solve(target, co);
+    RgbSolver::to_nm(co, out_c3);
     return 0;
+}
+
+// The table the reference loads from src/util/rgbspectrum_srgb.txt (missing upstream), regenerated the way pbrt's
+// rgb2spec_opt builds it: z_nodes[k] = smoothstep(smoothstep(k/63)); for each max-component l and each (y, x), the
+// brightness axis is swept outwards from k = 64/5 with warm starts.  Layout = CoefficientTable's
+// (color/color_space.rs:200-212): index ((l*64 + z)*64 + y)*64 + x, 3 coefficients each.
+int pmh_rgb_table_generate(const float* cie_x, const float* cie_y, const float* cie_z, const float* illuminant471,
+                           const float* xyz_from_rgb9, float* z_nodes64, float* coeffs, int nthreads) {
+    const int R = 64;
+    RgbSolver sv(cie_x, cie_y, cie_z, illuminant471, xyz_from_rgb9);
+    if (!sv.ok) return 1;
+    auto smoothstep = [](double x) { return x * x * (3.0 - 2.0 * x); };
+    std::vector<double> scale(R);
+    for (int k = 0; k < R; ++k) { scale[k] = smoothstep(smoothstep((double)k / (R - 1))); z_nodes64[k] = (float)scale[k]; }
+    auto column = [&](int l, int j, int i) {
+        const double x = (double)i / (R - 1), y = (double)j / (R - 1);
+        const int start = R / 5;
+        auto at = [&](int k, double* co) {
+            const double b = scale[k];
+            double rgb[3];
+            rgb[l] = b; rgb[(l + 1) % 3] = x * b; rgb[(l + 2) % 3] = y * b;
+            sv.solve(rgb, co);
+            RgbSolver::to_nm(co, coeffs + 3 * ((((size_t)l * R + k) * R + j) * R + i));
+        };
+        double co[3] = {0, 0, 0};
+        for (int k = start; k < R; ++k) at(k, co);
+        co[0] = co[1] = co[2] = 0;
+        for (int k = start; k >= 0; --k) at(k, co);
+    };
+    nthreads = std::max(1, nthreads);
+    std::vector<std::thread> th;
+    std::atomic<int> next(0);
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&]() {
+            for (;;) {
+                const int w = next.fetch_add(1);
+                if (w >= 3 * R) break;
+                const int l = w / R, j = w % R;
+                for (int i = 0; i < R; ++i) column(l, j, i);
+            }
+        });
+    for (auto& t : th) t.join();
+    return 0;
+}
+
+// RGBToSpectrumTable::convert (color/color_space.rs:128-185), f32, same operations in the same order
+void pmh_rgb_table_lookup(const float* z_nodes64, const float* coeffs, const float* rgb3_in, float* out_c3) {
+    const int R = 64;
+    const float rgb[3] = {rgb3_in[0] < 0.0f ? 0.0f : rgb3_in[0], rgb3_in[1] < 0.0f ? 0.0f : rgb3_in[1], rgb3_in[2] < 0.0f ? 0.0f : rgb3_in[2]};
+    if (rgb[0] == rgb[1] && rgb[1] == rgb[2]) {
+        out_c3[0] = 0.0f; out_c3[1] = 0.0f; out_c3[2] = (rgb[0] - 0.5f) / std::sqrt(rgb[0] * (1.0f - rgb[0]));
+        return;
+    }
+    const int max_i = rgb[0] > rgb[1] ? (rgb[0] > rgb[2] ? 0 : 2) : (rgb[1] > rgb[2] ? 1 : 2);
+    const float z = rgb[max_i];
+    const float x = rgb[(max_i + 1) % 3] * (float)(R - 1) / z;
+    const float y = rgb[(max_i + 2) % 3] * (float)(R - 1) / z;
+    const int xi = std::min((int)x, R - 2), yi = std::min((int)y, R - 2);
+    int zi;
+    {   // find_interval(64, |i| z_nodes[i] < z)  (util/routines.rs:1-32)
+        int left = 0, right = R - 1;
+        while (left < right) { const int mid = left + (right - left) / 2; if (z_nodes64[mid] < z) left = mid + 1; else right = mid; }
+        zi = left == 0 ? 0 : (left >= R - 1 ? R - 2 : left - 1);
+    }
+    const float dx = x - (float)xi, dy = y - (float)yi;
+    const float dz = (z - z_nodes64[zi]) / (z_nodes64[zi + 1] - z_nodes64[zi]);
+    auto lerp = [](float a, float b, float t) { return a * (1.0f - t) + b * t; };
+    for (int c = 0; c < 3; ++c) {
+        auto co = [&](int ddx, int ddy, int ddz) {
+            return coeffs[3 * ((((size_t)max_i * R + (zi + ddz)) * R + (yi + ddy)) * R + (xi + ddx)) + c];
+        };
+        out_c3[c] = lerp(lerp(lerp(co(0, 0, 0), co(1, 0, 0), dx), lerp(co(0, 1, 0), co(1, 1, 0), dx), dy),
+                         lerp(lerp(co(0, 0, 1), co(1, 0, 1), dx), lerp(co(0, 1, 1), co(1, 1, 1), dx), dy), dz);
+    }
 }
 
 // RGBColorSpace::new for sRGB primaries (color/color_space.rs:40-89): xyz_from_rgb and rgb_from_xyz (f32)

@@ -78,7 +78,11 @@ Transform.IDENTITY = Transform(np.eye(4), np.eye(4))
 class Spectra:
     """CIE tables, the sRGB colour space illuminant and the spectrum constructors of sampling/spectrum.rs."""
 
-    def __init__(self):
+    def __init__(self, rgb_mode="table"):
+        if rgb_mode not in ("table", "direct"):
+            raise ValueError(rgb_mode)
+        self.rgb_mode = rgb_mode
+        self._table = None
         d = np.load(_DATA)
         self.cie_x, self.cie_y, self.cie_z = (_f32(d[k]) for k in ("cie_x", "cie_y", "cie_z"))
         d65i = _f32(d["d65_interleaved"])
@@ -94,10 +98,46 @@ class Spectra:
     def photometric(self, table):
         return float(_capi.lib().pmh_photometric(_p(self.cie_y), _p(_f32(table))))
 
+    # ---- RGBColorSpace::to_rgb_coeffs (color/color_space.rs:110-184) -------------------------------------------
+    # The reference interpolates a 3 x 64^3 coefficient table read from src/util/rgbspectrum_srgb.txt, a file missing
+    # from the snapshot.  The table is regenerated here (pmh_rgb_table_generate, ~10 s once, cached next to the CIE
+    # tables) and looked up exactly as RGBToSpectrumTable::convert does; scripts/gen_rgbspectrum_table.py writes the same
+    # table in the text format the reference loads.  rgb_mode="direct" solves each colour without the table instead.
+    TABLE_PATH = os.path.join(os.path.dirname(_DATA), "rgbspectrum_srgb.bin")
+    _TABLE_MAGIC = b"PMRGBT1\0"
+
+    def rgb_table(self):
+        if self._table is None:
+            n = 3 * 64 ** 3 * 3
+            path = self.TABLE_PATH
+            if os.path.exists(path) and os.path.getsize(path) == 8 + 4 * (64 + n):
+                raw = np.fromfile(path, np.float32, offset=8)
+                z, co = raw[:64].copy(), raw[64:].copy()
+            else:
+                z, co = np.zeros(64, np.float32), np.zeros(n, np.float32)
+                threads = min(16, len(os.sched_getaffinity(0)))
+                if _capi.lib().pmh_rgb_table_generate(_p(self.cie_x), _p(self.cie_y), _p(self.cie_z), _p(self.d65),
+                                                      _p(self.xyz_from_rgb), _p(z), _p(co), threads) != 0:
+                    raise RuntimeError("rgb table generation failed")
+                try:
+                    tmp = f"{path}.{os.getpid()}.tmp"
+                    with open(tmp, "wb") as f:
+                        f.write(self._TABLE_MAGIC)
+                        f.write(z.tobytes())
+                        f.write(co.tobytes())
+                    os.replace(tmp, path)
+                except OSError:
+                    pass          # read-only tree: keep the table in memory only
+            self._table = (z, co)
+        return self._table
+
     def rgb_coeffs(self, rgb):
-        """RGBColorSpace::to_rgb_coeffs for sRGB (solved, not looked up: the table file is missing upstream)."""
         out = np.zeros(3, np.float32)
         rgb = _f32(np.maximum(rgb, 0))
+        if self.rgb_mode == "table":
+            z, co = self.rgb_table()
+            _capi.lib().pmh_rgb_table_lookup(_p(z), _p(co), _p(rgb), _p(out))
+            return out
         rc = _capi.lib().pmh_rgb_to_coeffs(_p(rgb), _p(self.cie_x), _p(self.cie_y), _p(self.cie_z), _p(self.d65),
                                            _p(self.xyz_from_rgb), _p(out))
         if rc != 0:
