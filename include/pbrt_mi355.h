@@ -50,8 +50,10 @@ typedef struct PmSphere {
     uint32_t _pad;
 } PmSphere;
 
-/* primitives/aggregates.rs:664-676 BVHSplitMethod.  The GPU tree is always a wide (8-ary) quantised
- * BVH built with binned SAH; the value is accepted for interface parity and recorded only. */
+/* primitives/aggregates.rs:664-676 BVHSplitMethod.  The tree is always a wide (8-ary) quantised BVH.  SAH, MIDDLE and
+ * EQUAL_COUNTS build it on the host with binned SAH (the value is recorded only: closest-hit results do not depend on
+ * the tree).  HLBVH builds a linear BVH ON THE DEVICE (Morton codes, radix sort, radix tree, refit, collapse) when the
+ * scene holds only triangles (>= 4096 of them) and the context owns a GPU; otherwise it falls back to the host build. */
 enum { PM_SPLIT_HLBVH = 0, PM_SPLIT_SAH = 1, PM_SPLIT_MIDDLE = 2, PM_SPLIT_EQUAL_COUNTS = 3 };
 
 typedef struct PmAccelInfo {

@@ -45,6 +45,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR void trace_kernel(const P
     if (tc.overflow) atomicAdd(&counters[3], 1ull);
 }
 
+int pm_gpu_build_tris(pm_ctx* c, int max_leaf, std::string& err);   // pm_gpu_build.hip
+
 // ------------------------------------------------------------------------------------------ lifetime
 extern "C" int pm_create(int device_id, pm_ctx** out) {
     if (!out) return PM_ERR_INVALID;
@@ -195,10 +197,18 @@ extern "C" int pm_build_accel(pm_ctx* c, int split_method, int max_prims_in_node
     if (c->device >= 0) HIPCHK(c, hipSetDevice(c->device));
     c->split_method = split_method;
     std::string err;
+    // PM_SPLIT_HLBVH on a GPU context: linear BVH built on the device (pm_gpu_build.hip) for triangle scenes
+    bool built_on_gpu = false;
+    if (split_method == PM_SPLIT_HLBVH && c->device >= 0) {
+        const int rc = pm_gpu_build_tris(c, max_prims_in_node, err);
+        if (rc == PM_OK) built_on_gpu = true;
+        else if (rc != PM_ERR_UNSUPPORTED) return fail(c, rc, "pm_build_accel: " + err);
+    }
     // the reference's max_prims_in_node is u8 (main.rs passes 255); wide leaves hold at most PM_MAX_LEAF
-    if (pm::build_accel(c->scene, max_prims_in_node, c->accel, err) != 0) return fail(c, PM_ERR_INVALID, "pm_build_accel: " + err);
+    if (!built_on_gpu && pm::build_accel(c->scene, max_prims_in_node, c->accel, err) != 0)
+        return fail(c, PM_ERR_INVALID, "pm_build_accel: " + err);
     const size_t nb = c->accel.nodes.size() * sizeof(PmWideNode), pb = c->accel.prims.size();
-    if (c->device >= 0) {
+    if (c->device >= 0 && !built_on_gpu) {
         if (c->d_nodes) { HIPCHK(c, hipFree(c->d_nodes)); c->d_nodes = nullptr; }
         if (c->d_prims) { HIPCHK(c, hipFree(c->d_prims)); c->d_prims = nullptr; }
         HIPCHK(c, hipMalloc((void**)&c->d_nodes, nb));
