@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="path workload: skip the C3 closest-hit figure")
     ap.add_argument("--cpu-sample", type=int, default=1 << 21, help="rays in the bounded CPU-baseline sample (trace)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time bound (path)")
+    ap.add_argument("--split", default="sah", choices=["sah", "hlbvh"],
+                    help="BVH build: binned SAH on the host (default) or the linear BVH built on the device (triangle scenes)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
                                                        "several ranks on one GPU)")
     return ap.parse_args()
@@ -116,7 +118,8 @@ def cpu_baseline_path(pm, sd, spp, max_depth, threads, seconds):
 def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, want_cpu):
     res = args.res or 4096
     pos, idx = pm.scenes.blob_mesh(args.blobs, 1024, seed=1)
-    agg = pm.GpuAggregate([pm.TriangleMesh(pos, idx)], device_id=local_rank)
+    split = pm._capi.PM_SPLIT_HLBVH if args.split == "hlbvh" else pm._capi.PM_SPLIT_SAH
+    agg = pm.GpuAggregate([pm.TriangleMesh(pos, idx)], device_id=local_rank, split_method=split)
     rays = pm.scenes.primary_rays(res, res, eye=(0.02 * rank, 0.0, -4.0))
     n_rays = len(rays)
     d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
@@ -161,6 +164,7 @@ def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, wan
         "config": {"workload": f"C3 closest-hit microbench: {len(idx)} triangles ({args.blobs} blobs x 1024), "
                                f"{res}x{res} primary rays per GPU in 8x8 tile order",
                    "rays_per_gpu": n_rays, "hit_fraction": hit_frac, "bvh_nodes": int(agg.info.n_nodes),
+                   "bvh_build": args.split, "bvh_build_seconds": float(agg.info.build_seconds),
                    "bvh_node_bytes": int(s_node), "tri_record_bytes": int(s_prim)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("trace_kernel<false, false>", "trace")[0],
@@ -211,7 +215,8 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup):
         spp = args.spp
         name = f"C2 Cornell box path tracing: {rw}x{rh} @ {spp} spp per GPU"
     spp_total = spp * world
-    integ = pm.WavefrontIntegrator(args.max_depth, True, True, sd, spp_total, seed=0, device_id=local_rank)
+    integ = pm.WavefrontIntegrator(args.max_depth, True, True, sd, spp_total, seed=0, device_id=local_rank,
+                                   split_method=pm._capi.PM_SPLIT_HLBVH if args.split == "hlbvh" else pm._capi.PM_SPLIT_SAH)
     s0, s1 = pm.distributed.shard_samples(spp_total, rank, world)
     film = torch.empty((rh, rw, 4), dtype=torch.float64, device="cuda")
 
@@ -264,7 +269,8 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{name}, SimplePathIntegrator max_depth {args.max_depth}, light + BSDF sampling, "
                                f"Gaussian filter, 4 wavelengths/sample",
-                   "bvh_nodes": int(integ.aggregate.info.n_nodes), "bvh_build_seconds": float(integ.aggregate.info.build_seconds),
+                   "bvh_nodes": int(integ.aggregate.info.n_nodes), "bvh_build": args.split,
+                   "bvh_build_seconds": float(integ.aggregate.info.build_seconds),
                    "samples_per_gpu": samples, "closest_rays": st["closest_rays"], "shadow_rays": st["shadow_rays"],
                    "passes": st["passes"], "merge": "none" if world == 1 else "RCCL all-reduce of the f64 film per step",
                    "bytes_per_sample": total_bytes / samples,

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 
 #include "pm_ctx.h"
 
@@ -282,8 +283,14 @@ int pm_gpu_build_tris(pm_ctx* c, int max_leaf, std::string& err) {
     const size_t n = sc.tris.size();
     if (!sc.spheres.empty() || !sc.patches.empty() || n < 4096 || n > 0x3FFFFFFFull / PM_UNITS_TRI) return PM_ERR_UNSUPPORTED;
     const auto t0 = std::chrono::steady_clock::now();
-    if (max_leaf < 1) max_leaf = 1;
-    if (max_leaf > PM_MAX_LEAF) max_leaf = PM_MAX_LEAF;
+    // Leaves of a linear BVH are runs of the Morton order, not SAH clusters: their boxes are loose, and every extra
+    // primitive in a leaf is an extra pre-filter test for each ray that touches the box.  Measured on the C3 geometry
+    // (scripts/gpu_build_probe.py, profiles/r01/gpu_build_probe.log): leaves of <= 4 / 2 / 1 primitives give
+    // 26.4 / 10.9 / 4.3 tests per ray and 954 / 1237 / 1461 Mrays/s, so the device build uses single-primitive leaves
+    // whatever max_prims_in_node says (PBRT_MI355_LBVH_LEAF overrides, for experiments).
+    (void)max_leaf;
+    max_leaf = 1;
+    if (const char* e = std::getenv("PBRT_MI355_LBVH_LEAF")) { const int v = std::atoi(e); if (v >= 1 && v <= PM_MAX_LEAF) max_leaf = v; }
     GBox scene;
     for (int k = 0; k < 3; ++k) { scene.lo[k] = INFINITY; scene.hi[k] = -INFINITY; }
     for (const auto& t : sc.tris)

@@ -12,9 +12,11 @@ for blobs in [int(a) for a in sys.argv[1:]] or [1024]:
     d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
     d_hits = torch.empty((len(rays), 4), dtype=torch.float32, device="cuda")
     res = {}
-    for name, m in (("hlbvh_gpu", pm._capi.PM_SPLIT_HLBVH), ("sah_host", pm._capi.PM_SPLIT_SAH)):
+    for name, m, leaf in (("hlbvh_gpu", pm._capi.PM_SPLIT_HLBVH, 4), ("hlbvh_gpu2", pm._capi.PM_SPLIT_HLBVH, 2),
+                          ("hlbvh_gpu1", pm._capi.PM_SPLIT_HLBVH, 1), ("sah_host", pm._capi.PM_SPLIT_SAH, 4),
+                          ("sah_host2", pm._capi.PM_SPLIT_SAH, 2), ("sah_host1", pm._capi.PM_SPLIT_SAH, 1)):
         t0 = time.time()
-        agg = pm.GpuAggregate([pm.TriangleMesh(pos, idx)], split_method=m)
+        agg = pm.GpuAggregate([pm.TriangleMesh(pos, idx)], split_method=m, max_prims_in_node=leaf)
         wall = time.time() - t0
         agg.set_counting(True); agg.reset_counters(); agg.intersect(d_rays, out=d_hits); c = agg.counters(); agg.set_counting(False)
         agg.intersect(d_rays, out=d_hits)
