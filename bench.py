@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--blobs", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="path workload: skip the C3 closest-hit figure")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 21, help="rays in the bounded CPU-baseline sample (trace)")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="rays in the bounded CPU-baseline sample (trace; about 20 core-seconds)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time bound (path)")
     ap.add_argument("--split", default="sah", choices=["sah", "hlbvh"],
                     help="BVH build: binned SAH on the host (default) or the linear BVH built on the device (triangle scenes)")
@@ -172,6 +172,46 @@ def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, wan
                      "kernel": "trace_kernel<false,false>", "kernel_ms": k_ms,
                      "bytes_per_ray": bytes_per_ray, "nodes_per_ray": n_node, "prims_per_ray": n_prim},
     }
+    if not args.no_secondary:
+        # SURVEY.md 8(d) C3's other two ray sets, each with its own counters and event-timed launches (not `value`)
+        hits_host = np.empty(n_rays, dtype=pm.HIT_DTYPE)
+        hits_host.view(np.float32).reshape(-1, 4)[:] = d_hits.cpu().numpy()
+        sets = [("shadow_any_hit", pm.scenes.shadow_rays(rays, hits_host), True,
+                 "any hit from every primary hit point towards a point light at (0,3,0), un-normalised direction, "
+                 "t_max = 1 - 1e-4 (primary misses carry t_max = 0)"),
+                ("incoherent_closest_hit", pm.scenes.incoherent_rays(n_rays, seed=2 + rank), False,
+                 "closest hit, origins uniform on a sphere of radius 1.9 around the mesh, directions cosine-distributed "
+                 "about the inward normal, in generation order (no sorting)")]
+        for key, rset, any_hit, what in sets:
+            note(f"secondary ray set: {key}")
+            d_r = torch.from_numpy(rset.view(np.float32).reshape(-1, 8)).cuda()
+            d_o = (torch.empty(n_rays, dtype=torch.uint8, device="cuda") if any_hit
+                   else torch.empty((n_rays, 4), dtype=torch.float32, device="cuda"))
+            call = agg.intersect_p if any_hit else agg.intersect
+            agg.set_counting(True)
+            agg.reset_counters()
+            call(d_r, out=d_o)
+            c2 = agg.counters()
+            agg.set_counting(False)
+            for _ in range(max(1, warmup)):
+                call(d_r, out=d_o)
+            ms = []
+            for _ in range(steps):
+                call(d_r, out=d_o)
+                ms.append(agg.last_kernel_ms())
+            ms = float(np.mean(ms))
+            live = int((rset["tmax"] > 0).sum())
+            nn, npr = c2["nodes_visited"] / n_rays, c2["prims_tested"] / n_rays
+            bpr = 32 + (1 if any_hit else 16) + nn * s_node + npr * s_prim
+            ach = bpr * n_rays / (ms * 1e-3) / 1e9
+            frac_out = (float(d_o.float().mean().item()) if any_hit
+                        else float((d_o[:, 0].view(torch.int32) != -1).float().mean().item()))
+            out[key] = {"value": n_rays / (ms * 1e-3) / 1e6, "unit": "Mrays/s (this GPU, event-timed kernel)", "rays": what,
+                        "kernel_ms": ms, "live_rays": live, "occluded_or_hit_fraction": frac_out,
+                        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": ach / HBM_PEAK_GBS, "bytes_per_ray": bpr, "nodes_per_ray": nn,
+                                     "prims_per_ray": npr, "fallback_walks": c2["fallback_walks"]}}
+            del d_r, d_o
     if want_cpu and rank == 0:
         threads = min(16, len(os.sched_getaffinity(0)))
         out["cpu_baseline"] = cpu_baseline_trace(pos, idx, rays[:args.cpu_sample], threads)
@@ -327,6 +367,9 @@ def main():
             tr = run_trace(args, pm, torch, dist, rank, local_rank, world, max(3, args.steps), 1, False)
             out["closest_hit"] = {"value": tr["value"], "unit": tr["unit"], "workload": tr["config"]["workload"],
                                   "ms_per_step": tr["ms_per_step"], "roofline": tr["roofline"]}
+            for key in ("shadow_any_hit", "incoherent_closest_hit"):
+                if key in tr:
+                    out["closest_hit"][key] = tr[key]
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
