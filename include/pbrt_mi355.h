@@ -63,6 +63,11 @@ typedef struct PmAccelInfo {
     uint64_t node_buffer_bytes, prim_buffer_bytes;
     float bounds[6];              /* aggregate bounds(): min xyz, max xyz */
     double build_seconds;
+    uint32_t flat_prims;          /* != 0: the scene is small enough (<= 64 primitives) that rays sweep all of them in lock
+                                   * step instead of walking the tree; then nodes_visited stays 0 and prims_tested counts
+                                   * every primitive the sweep offers a ray.  PBRT_MI355_FLAT_MAX=0 in the environment
+                                   * disables it (checked by pm_build_accel). */
+    uint32_t reserved;
 } PmAccelInfo;
 
 /* deterministic traversal counters: totals since pm_reset_counters */

@@ -45,7 +45,7 @@ def lib():
             "ora_build": (i, [p, i, i]), "ora_scene_bounds": (None, [p, p]),
             "ora_trace_closest": (None, [p, p, u64, p, p, i, i]),
             "ora_trace_any": (None, [p, p, u64, p, p, i]),
-            "ora_wide_trace": (None, [p, p, p, u64, p, i, p, i]),
+            "ora_wide_trace": (None, [p, p, p, u64, p, i, p, i, i]),
             "ora_next_float_up": (f, [f]), "ora_next_float_down": (f, [f]), "ora_gamma": (f, [i]),
             "ora_exponent": (i, [f]), "ora_fast_exp": (f, [f]), "ora_gaussian": (f, [f, f, f]),
             "ora_erf_inv": (f, [f]), "ora_evaluate_polynomial": (f, [f, p, i]),
@@ -121,13 +121,14 @@ class Scene:
             pass
 
 
-def wide_trace(node_buf, prim_buf, rays, any_hit=False, nthreads=8):
-    """Walk the GPU-layout tree on the CPU; returns (hits or occlusion, counters)."""
+def wide_trace(node_buf, prim_buf, rays, any_hit=False, nthreads=8, flat=False):
+    """Walk the GPU-layout tree on the CPU; returns (hits or occlusion, counters).  flat: sweep all primitives without
+    the tree, as the kernels do for scenes with PmAccelInfo.flat_prims != 0."""
     assert rays.dtype == RAY_DTYPE
     out = np.empty(len(rays), np.uint8 if any_hit else HIT_DTYPE)
     ctr = np.zeros(4, np.uint64)
     lib().ora_wide_trace(node_buf.ctypes.data, prim_buf.ctypes.data, rays.ctypes.data, len(rays), out.ctypes.data,
-                         int(any_hit), ctr.ctypes.data, nthreads)
+                         int(any_hit), ctr.ctypes.data, nthreads, int(bool(flat)))
     return out, {"nodes_visited": int(ctr[0]), "prims_tested": int(ctr[1]), "exact_tests": int(ctr[2]),
                  "fallback_walks": int(ctr[3])}
 

@@ -151,15 +151,20 @@ void ora_trace_any(OraScene* s, const OraRay* rays, uint64_t n, uint8_t* out, ui
 }
 
 // Walk the GPU-layout wide BVH on the CPU (same order as the HIP kernel).  any_hit: out is uint8[n], else OraHit[n].
+// flat != 0: the scene is swept without the tree, as the kernels do for PmAccelInfo.flat_prims != 0.
 void ora_wide_trace(const void* nodes, const void* prims, const OraRay* rays, uint64_t n, void* out, int any_hit,
-                    uint64_t* counters4, int nthreads) {
+                    uint64_t* counters4, int nthreads, int flat) {
     WideWalker ww{reinterpret_cast<const WNode*>(nodes), reinterpret_cast<const uint8_t*>(prims)};
+    WideWalker::FlatTable ft;
+    if (flat) ft = ww.flat_table();
     std::vector<Counters> ctr(std::max(1, nthreads));
     parallel_chunks(n, nthreads, [&](uint64_t b, uint64_t e, int tid) {
         for (uint64_t i = b; i < e; ++i) {
             const OraRay& r = rays[i];
             uint32_t id; float t, u, v;
-            bool f = ww.walk(V3(r.o[0], r.o[1], r.o[2]), V3(r.d[0], r.d[1], r.d[2]), r.tmax, any_hit != 0, &id, &t, &u, &v, &ctr[tid]);
+            const V3 ro(r.o[0], r.o[1], r.o[2]), rd(r.d[0], r.d[1], r.d[2]);
+            bool f = flat ? ww.walk_flat(ft, ro, rd, r.tmax, any_hit != 0, &id, &t, &u, &v, &ctr[tid])
+                          : ww.walk(ro, rd, r.tmax, any_hit != 0, &id, &t, &u, &v, &ctr[tid]);
             if (any_hit) reinterpret_cast<uint8_t*>(out)[i] = f ? 1 : 0;
             else { OraHit& h = reinterpret_cast<OraHit*>(out)[i]; h.prim_id = id; h.t = t; h.u = u; h.v = v; }
         }

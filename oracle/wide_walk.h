@@ -33,6 +33,7 @@ static inline uint32_t perm8(uint32_t m, uint32_t oct) {
 struct WideWalker {
     const WNode* nodes;
     const uint8_t* prims;   // 16-byte units
+    bool defer_spheres = true;   // GPU contexts defer spheres that pass the float pre-filter to a second pass
 
     bool test_prim(uint32_t type, uint32_t unit, V3 ro, V3 rd, float t_max, uint32_t* id, float* t, float* u, float* v) const {
         const float* f = reinterpret_cast<const float*>(prims + (size_t)unit * 16);
@@ -66,14 +67,46 @@ struct WideWalker {
     }
     static float fdot(V3 a, V3 b) { return std::fmaf(a.z, b.z, std::fmaf(a.y, b.y, a.x * b.x)); }
     static float maxabs(V3 a) { float m = std::fabs(a.x); float y = std::fabs(a.y), z = std::fabs(a.z); if (!(y < m)) m = y; if (!(z < m)) m = z; return m; }
-    static int tri_prefilter(V3 ro, V3 rd, float R, float D, V3 v0, V3 v1, V3 v2, float tcull, float* t_hi) {
-        const float K = 7.62939453125e-06f;
+    static int tri_prefilter(V3 ro, V3 rd, float R, float D, V3 v0, V3 v1, V3 v2, float tcull, float* t_hi, float* t_lo) {
         V3 e1 = v1 - v0, e2 = v2 - v0, sv = ro - v0;
         V3 pv = fcross(rd, e2);
         float det = fdot(e1, pv), uu = fdot(sv, pv);
         V3 qv = fcross(sv, e1);
         float vv = fdot(rd, qv), tt = fdot(e2, qv);
         float L = rmax(maxabs(e1), maxabs(e2)), S = maxabs(sv);
+        return tri_classify(det, uu, vv, tt, L, S, R, D, tcull, t_hi, t_lo);
+    }
+    // pm_device.hpp tri_prefilter_flat: the same triple products from the flat-table entry (e1, e2, n = e1 x e2, L, c1, kll),
+    // no division: the culling distance is the fraction cn / cd, the candidate's lower bound the fraction ln / ld
+    struct FlatCull { float cn, cd; };
+    static int tri_prefilter_flat(V3 ro, V3 rd, float KD, float R2, V3 v0, V3 e1, V3 e2, V3 n, float L, float c1, float kll,
+                                  float epsb_ray, FlatCull* cull, bool lower, float* ln, float* ld) {
+        V3 sv = ro - v0;
+        V3 m = fcross(sv, rd);
+        float uu = fdot(e2, m), vv = -fdot(e1, m), det = -fdot(rd, n), tt = fdot(sv, n);
+        if (det < 0.0f) { det = -det; uu = -uu; vv = -vv; tt = -tt; }
+        const float Sx = R2 + c1;
+        const float tb = (KD * L) * Sx;
+        const float ttau = kll * Sx;
+        const float dp = det + tb;
+        const bool reject = (uu < -tb) | (vv < -tb) | (uu + vv > dp + tb) | (tt < -ttau) | ((tt - ttau) * cull->cd > cull->cn * dp);
+        if (reject) return 0;
+        *ln = 0.0f; *ld = 1.0f;
+        if ((uu > tb) & (vv > tb) & (uu + vv < (det - tb) - tb) & (det > 2.0f * tb) & (tt > ttau)) {
+            const float hn = (tt + ttau) * 1.00001f, hd = det - tb;
+            const float lo = (tt - ttau) * 0.99999f;
+            const float epsb = std::fmaf(3.2e-6f, c1, epsb_ray);
+            if ((lo > epsb * dp) & (hn * cull->cd < cull->cn * hd)) {
+                if (lower) { cull->cn = hn; cull->cd = hd; }
+                *ln = lo; *ld = dp;
+                return 2;
+            }
+        }
+        return 1;
+    }
+    static int tri_classify(float det, float uu, float vv, float tt, float L, float S, float R, float D, float tcull, float* t_hi,
+                            float* t_lo) {
+        const float K = 7.62939453125e-06f;
         if (det < 0.0f) { det = -det; uu = -uu; vv = -vv; tt = -tt; }
         float Sx = S + R + L;
         float tb = K * D * L * Sx;
@@ -81,15 +114,156 @@ struct WideWalker {
         if (uu < -tb || vv < -tb || uu + vv > det + 2.0f * tb) return 0;
         if (tt < -ttau) return 0;
         if (tt > std::fmaf(tcull, det + tb, ttau)) return 0;
+        *t_lo = 0.0f;
         if (uu > tb && vv > tb && uu + vv < det - 2.0f * tb && det > 2.0f * tb && tt > ttau) {
             float epsb = 8e-7f * (5.0f * R + D + 4.0f * (S + L));
             float th = ((tt + ttau) / (det - tb)) * 1.00001f;
             float tl = ((tt - ttau) / (det + tb)) * 0.99999f;
-            if (tl > epsb && th < tcull) { *t_hi = th; return 2; }
+            if (tl > epsb && th < tcull) { *t_hi = th; *t_lo = tl; return 2; }
         }
         return 1;
     }
+    // ---- the kernel's float pre-filter for spheres, operation for operation (pm_device.hpp sphere_prefilter)
+    static bool sphere_prefilter(V3 ro, V3 rd, float R, float D, const float* m, float radius, float m_norm, float t_norm, float tcull) {
+        const float EPS = 4.76837158203125e-07f;
+        V3 o(std::fmaf(m[0], ro.x, std::fmaf(m[1], ro.y, std::fmaf(m[2], ro.z, m[3]))),
+             std::fmaf(m[4], ro.x, std::fmaf(m[5], ro.y, std::fmaf(m[6], ro.z, m[7]))),
+             std::fmaf(m[8], ro.x, std::fmaf(m[9], ro.y, std::fmaf(m[10], ro.z, m[11]))));
+        V3 d(std::fmaf(m[0], rd.x, std::fmaf(m[1], rd.y, m[2] * rd.z)),
+             std::fmaf(m[4], rd.x, std::fmaf(m[5], rd.y, m[6] * rd.z)),
+             std::fmaf(m[8], rd.x, std::fmaf(m[9], rd.y, m[10] * rd.z)));
+        float a = fdot(d, d), b = fdot(o, d), oo = fdot(o, o), rr = radius * radius;
+        float c = oo - rr;
+        float Om = rmax(rmax(std::fabs(o.x), std::fabs(o.y)), std::fabs(o.z)), Dm = rmax(rmax(std::fabs(d.x), std::fabs(d.y)), std::fabs(d.z));
+        float eo = EPS * std::fmaf(m_norm, R, t_norm);
+        float ed = EPS * (m_norm * D);
+        float db = 3.0f * std::fmaf(Om, ed, Dm * eo);
+        float dc = 6.0f * (Om * eo), da = 6.0f * (Dm * ed);
+        float base = EPS * std::fmaf(a, oo + rr, b * b);
+        float disc = std::fmaf(b, b, -(a * c));
+        float E = 4.0f * (std::fmaf(2.0f * std::fabs(b), db, std::fmaf(a, dc, std::fabs(c) * da)) + base);
+        if (disc < -E) return false;
+        float cl = c - 2.0f * std::fmaf(EPS, oo + rr, dc);
+        if (cl > 0.0f) {
+            if (b > db) return false;
+            float den = (db - b) + std::sqrt(rmax(disc, 0.0f) + E) * 1.000001f;
+            if (den > 0.0f && (cl / den) * 0.99999f > tcull) return false;
+        }
+        return true;
+    }
     static uint32_t nonzero_meta_mask(const WNode& nd) { uint32_t m = 0; for (int s = 0; s < 8; ++s) if (nd.meta[s]) m |= 1u << s; return m; }
+
+    // ---- flat sweep (pm_device.hpp trace_flat) for scenes of at most PM_FLAT_MAX_PRIMS primitives.  The table is derived
+    // from the exported buffers exactly as pm_build.cpp build_flat_table derives it: node index, slot, record order.
+    struct FlatTri { V3 v0, e1, e2, n; float L, c1, kll; uint32_t unit; };
+    struct FlatTable { std::vector<uint32_t> spheres, patches; std::vector<FlatTri> tris; };
+    FlatTable flat_table() const {
+        uint32_t n_nodes = 1;
+        for (uint32_t i = 0; i < n_nodes; ++i) {
+            const WNode& nd = nodes[i];
+            if (nd.imask) n_nodes = std::max(n_nodes, nd.child_base + (uint32_t)__builtin_popcount(nd.imask));
+        }
+        FlatTable ft;
+        for (uint32_t i = 0; i < n_nodes; ++i) {
+            const WNode& nd = nodes[i];
+            const uint32_t type = nd.prim_base >> 30, pbase = nd.prim_base & 0x3FFFFFFFu;
+            const uint32_t units = type == 2 ? 3 : (type == 1 ? 4 : 5);
+            for (int s = 0; s < 8; ++s) {
+                if ((nd.imask >> s) & 1) continue;
+                const uint32_t cnt = nd.meta[s] >> 5, off = nd.meta[s] & 31u;
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    const uint32_t unit = pbase + (off + j) * units;
+                    if (type == 0) ft.spheres.push_back(unit);
+                    else if (type == 1) ft.patches.push_back(unit);
+                    else {
+                        const float* f = reinterpret_cast<const float*>(prims + (size_t)unit * 16);
+                        FlatTri t;
+                        t.v0 = V3(f[0], f[1], f[2]);
+                        t.e1 = V3(f[3] - f[0], f[4] - f[1], f[5] - f[2]);
+                        t.e2 = V3(f[6] - f[0], f[7] - f[1], f[8] - f[2]);
+                        t.n = V3((float)((double)t.e1.y * (double)t.e2.z - (double)t.e1.z * (double)t.e2.y),
+                                 (float)((double)t.e1.z * (double)t.e2.x - (double)t.e1.x * (double)t.e2.z),
+                                 (float)((double)t.e1.x * (double)t.e2.y - (double)t.e1.y * (double)t.e2.x));
+                        t.L = rmax(maxabs(t.e1), maxabs(t.e2));
+                        t.c1 = maxabs(t.v0) + t.L;
+                        t.kll = (7.62939453125e-06f * t.L) * t.L;
+                        t.unit = unit;
+                        ft.tris.push_back(t);
+                    }
+                }
+            }
+        }
+        return ft;
+    }
+    bool walk_flat(const FlatTable& ft, V3 ro, V3 rd, float ray_tmax, bool any_hit, uint32_t* hid, float* ht, float* hu, float* hv,
+                   Counters* ctr) const {
+        *hid = 0xFFFFFFFFu; *ht = ray_tmax; *hu = 0; *hv = 0;
+        {
+            const float dsum = std::fabs(rd.x) + std::fabs(rd.y) + std::fabs(rd.z), osum = std::fabs(ro.x) + std::fabs(ro.y) + std::fabs(ro.z);
+            if (!(dsum > 0.0f && dsum < std::numeric_limits<float>::infinity() && osum < std::numeric_limits<float>::infinity())) return false;
+        }
+        const uint32_t CAND_MAX = 4;
+        const float R = maxabs(ro), D = maxabs(rd);
+        float t_max = ray_tmax, tcull = ray_tmax;
+        bool sure = false, found = false;
+        std::vector<uint32_t> deferred;
+        auto test_now = [&](uint32_t type, uint32_t unit) {
+            if (ctr) ctr->exact_tests++;
+            uint32_t id; float t, u, v;
+            if (test_prim(type, unit, ro, rd, t_max, &id, &t, &u, &v)) { t_max = t; found = true; *hid = id; *ht = t; *hu = u; *hv = v; return true; }
+            return false;
+        };
+        for (uint32_t unit : ft.spheres) {
+            if (any_hit && (found || sure)) break;
+            if (ctr) ctr->prims_tested++;
+            bool now = !defer_spheres;
+            if (!now) {
+                const float* f = reinterpret_cast<const float*>(prims + (size_t)unit * 16);
+                if (sphere_prefilter(ro, rd, R, D, f, f[12], f[18], f[19], tcull)) {
+                    if (deferred.size() < 2) deferred.push_back(unit); else now = true;
+                }
+            }
+            if (now && test_now(0, unit)) tcull = rmin(tcull, *ht);
+        }
+        for (uint32_t unit : ft.patches) {
+            if (any_hit && (found || sure)) break;
+            if (ctr) ctr->prims_tested++;
+            if (test_now(1, unit)) tcull = rmin(tcull, *ht);
+        }
+        struct Cand { uint32_t unit; float ln, ld; };
+        std::vector<Cand> cand;
+        FlatCull cull{tcull, 1.0f};
+        const float KD = 7.62939453125e-06f * D, R2 = 2.0f * R, epsb_ray = 8e-7f * std::fmaf(9.0f, R, D);
+        for (const FlatTri& t : ft.tris) {
+            if (any_hit && (found || sure)) break;
+            if (ctr) ctr->prims_tested++;
+            float ln, ld;
+            int cls = tri_prefilter_flat(ro, rd, KD, R2, t.v0, t.e1, t.e2, t.n, t.L, t.c1, t.kll, epsb_ray, &cull, !any_hit, &ln, &ld);
+            if (cls != 0) {
+                if (cls == 2) sure = true;
+                if (cand.size() < CAND_MAX) cand.push_back(Cand{t.unit, ln, ld});
+                else (void)test_now(2, t.unit);
+            }
+        }
+        for (const Cand& cu : cand) {
+            if (cu.ln * cull.cd > cull.cn * cu.ld) continue;        // behind another certain hit (filtered before the round)
+            if (any_hit && found) break;
+            (void)test_now(2, cu.unit);
+        }
+        if (sure && !(found && (any_hit || !(*ht * cull.cd > cull.cn)))) {        // exact re-sweep (never seen)
+            if (ctr) ctr->fallback_walks++;
+            t_max = ray_tmax; found = false; deferred.clear();
+            *hid = 0xFFFFFFFFu; *ht = ray_tmax; *hu = 0; *hv = 0;
+            for (uint32_t unit : ft.spheres) { if (any_hit && found) break; if (ctr) ctr->prims_tested++; (void)test_now(0, unit); }
+            for (uint32_t unit : ft.patches) { if (any_hit && found) break; if (ctr) ctr->prims_tested++; (void)test_now(1, unit); }
+            for (const FlatTri& t : ft.tris) { if (any_hit && found) break; if (ctr) ctr->prims_tested++; (void)test_now(2, t.unit); }
+        }
+        for (uint32_t unit : deferred) {                            // the kernel's second pass (sphere_fix)
+            if (any_hit && found) break;
+            (void)test_now(0, unit);
+        }
+        return found;
+    }
 
     // returns true if something was hit; closest-hit unless any_hit.  Mirrors pm_device.hpp traverse<>: pre-scaled slab test
     // with folded margins, triangle pre-filter + queue of PM_CAND_MAX candidates tested exactly after the walk, culling by
@@ -118,7 +292,8 @@ struct WideWalker {
         for (int attempt = 0; attempt < 2; ++attempt) {
             float t_max = ray_tmax, tcull = ray_tmax;
             bool sure = false;
-            std::vector<uint32_t> cand;
+            std::vector<std::pair<uint32_t, float>> cand;   // (record unit, lower bound of t: 0 unless a certain hit)
+            std::vector<uint32_t> deferred;     // spheres that passed the pre-filter: exact tests after everything else
             std::vector<Group> stack;
             Group cur{0u, 1u, perm8(1u, oct)};
             found = false;
@@ -171,14 +346,19 @@ struct WideWalker {
                         if (itrace && itrace->back() < 200) itrace->back()++;
                         uint32_t unit = pbase + (off + j) * units;
                         bool immediate = true;
+                        if (type == 0 && !exact_mode && defer_spheres) {
+                            const float* f = reinterpret_cast<const float*>(prims + (size_t)unit * 16);
+                            if (!sphere_prefilter(ro, rd, R, D, f, f[12], f[18], f[19], tcull)) immediate = false;
+                            else if (deferred.size() < 2) { deferred.push_back(unit); immediate = false; }
+                        }
                         if (type == 2 && !exact_mode) {
                             const float* f = reinterpret_cast<const float*>(prims + (size_t)unit * 16);
-                            float th;
-                            int cls = tri_prefilter(ro, rd, R, D, V3(f[0], f[1], f[2]), V3(f[3], f[4], f[5]), V3(f[6], f[7], f[8]), tcull, &th);
+                            float th, tl;
+                            int cls = tri_prefilter(ro, rd, R, D, V3(f[0], f[1], f[2]), V3(f[3], f[4], f[5]), V3(f[6], f[7], f[8]), tcull, &th, &tl);
                             if (cls == 0) immediate = false;
                             else {
                                 if (cls == 2) { sure = true; if (!any_hit) tcull = th; }
-                                if (cand.size() < CAND_MAX) { cand.push_back(unit); immediate = false; }
+                                if (cand.size() < CAND_MAX) { cand.emplace_back(unit, tl); immediate = false; }
                             }
                         }
                         if (immediate) {
@@ -193,14 +373,23 @@ struct WideWalker {
                 }
                 cur = Group{nd.child_base, nd.imask, perm8(hits & nd.imask, oct)};
             }
-            for (uint32_t unit : cand) {
+            for (const auto& cu : cand) {
                 if (any_hit && found) break;
+                if (cu.second > tcull) continue;        // behind another certain hit
                 if (ctr) ctr->exact_tests++;
                 uint32_t id; float t, u, v;
-                if (test_prim(2, unit, ro, rd, t_max, &id, &t, &u, &v)) { t_max = t; found = true; *hid = id; *ht = t; *hu = u; *hv = v; }
+                if (test_prim(2, cu.first, ro, rd, t_max, &id, &t, &u, &v)) { t_max = t; found = true; *hid = id; *ht = t; *hu = u; *hv = v; }
             }
             bool confirmed = !sure || (found && (any_hit || *ht <= tcull));
-            if (confirmed || exact_mode) break;
+            if (confirmed || exact_mode) {
+                for (uint32_t unit : deferred) {        // the kernel's second pass (sphere_fix)
+                    if (any_hit && found) break;
+                    if (ctr) ctr->exact_tests++;
+                    uint32_t id; float t, u, v;
+                    if (test_prim(0, unit, ro, rd, t_max, &id, &t, &u, &v)) { t_max = t; found = true; *hid = id; *ht = t; *hu = u; *hv = v; }
+                }
+                break;
+            }
             exact_mode = true;
             if (ctr) ctr->fallback_walks++;
         }

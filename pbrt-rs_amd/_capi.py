@@ -30,7 +30,8 @@ class PmSphere(C.Structure):
 class PmAccelInfo(C.Structure):
     _fields_ = [("n_prims", C.c_uint32), ("n_nodes", C.c_uint32), ("node_bytes", C.c_uint32),
                 ("prim_record_bytes", C.c_uint32 * 3), ("node_buffer_bytes", C.c_uint64),
-                ("prim_buffer_bytes", C.c_uint64), ("bounds", C.c_float * 6), ("build_seconds", C.c_double)]
+                ("prim_buffer_bytes", C.c_uint64), ("bounds", C.c_float * 6), ("build_seconds", C.c_double),
+                ("flat_prims", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class PmCounters(C.Structure):

@@ -6,15 +6,16 @@
 #include "pm_device.hpp"
 
 // ------------------------------------------------------------------------------------------ kernels
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool SPH>
 __global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR void trace_kernel(const PmWideNode* __restrict__ nodes,
                                                             const uint4* __restrict__ prims,
                                                             const PmRay* __restrict__ rays, uint32_t n,
                                                             PmHit* __restrict__ hits, uint8_t* __restrict__ occ,
                                                             uint32_t* __restrict__ work, uint32_t refill,
+                                                            uint4* __restrict__ defer_list,
                                                             unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TRACE_BLOCK];
-    __shared__ uint32_t cand[PM_CAND_MAX * TRACE_BLOCK];
+    __shared__ uint32_t cand[2 * PM_CAND_MAX * TRACE_BLOCK];     // units, then t lower bounds
     pmd::TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, pmd::Ray* ray) -> bool {
         const float4* rp = reinterpret_cast<const float4*>(rays + i);
@@ -30,7 +31,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR void trace_kernel(const P
             *reinterpret_cast<float4*>(hits + i) = o;
         }
     };
-    pmd::trace_persistent<ANY, COUNT>(nodes, prims, n, work, refill, stack + threadIdx.x, cand + threadIdx.x, TRACE_BLOCK, &tc, fetch, commit);
+    pmd::trace_persistent<ANY, COUNT, SPH>(nodes, prims, n, work, refill, stack + threadIdx.x, cand + threadIdx.x, TRACE_BLOCK,
+                                      defer_list, work + PM_WORK_SLOTS, &tc, fetch, commit);
     if (COUNT) {
         // wave-level reduction, one atomic per wave per counter
         unsigned long long nn = tc.nodes, pp = tc.prims, ee = tc.exact, ff = tc.fallback;
@@ -43,6 +45,67 @@ __global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR void trace_kernel(const P
         }
     }
     if (tc.overflow) atomicAdd(&counters[3], 1ull);
+}
+
+// the same entry points for scenes small enough to be swept without a tree (pm_device.hpp trace_flat)
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(TRACE_BLOCK) PM_FLAT_ATTR void trace_flat_kernel(PmFlatScene fs, const uint4* __restrict__ prims,
+                                                                 const PmRay* __restrict__ rays, uint32_t n,
+                                                                 PmHit* __restrict__ hits, uint8_t* __restrict__ occ,
+                                                                 uint4* __restrict__ defer_list, uint32_t* __restrict__ defer_count,
+                                                                 unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t cand[3 * PM_CAND_MAX * TRACE_BLOCK];     // units, then the lower bounds of t as fractions (numerators, denominators)
+    pmd::TravCounters tc = {0u, 0u, 0u, 0u, 0u};
+    auto fetch = [&](uint32_t i, pmd::Ray* ray) -> bool {
+        const float4* rp = reinterpret_cast<const float4*>(rays + i);
+        const float4 a = rp[0], b = rp[1];
+        ray->o = pmd::mk3(a.x, a.y, a.z); ray->tmax = a.w; ray->d = pmd::mk3(b.x, b.y, b.z);
+        return true;
+    };
+    auto commit = [&](uint32_t i, bool found, const pmd::HitRec& h) {
+        if (ANY) occ[i] = found ? 1 : 0;
+        else {
+            float4 o;
+            o.x = __uint_as_float(h.prim_id); o.y = h.t; o.z = h.u; o.w = h.v;
+            *reinterpret_cast<float4*>(hits + i) = o;
+        }
+    };
+    pmd::trace_flat<ANY, COUNT>(fs, prims, n, cand + threadIdx.x, TRACE_BLOCK, defer_list, defer_count, &tc, fetch, commit);
+    if (COUNT) {
+        unsigned long long pp = tc.prims, ee = tc.exact, ff = tc.fallback;
+        for (int off = 32; off > 0; off >>= 1) { pp += __shfl_down(pp, off); ee += __shfl_down(ee, off); ff += __shfl_down(ff, off); }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&counters[2], pp); atomicAdd(&counters[6], ee);
+            if (ff) atomicAdd(&counters[7], ff);
+        }
+    }
+}
+
+// exact tests of the spheres that trace_kernel deferred (pm_device.hpp sphere_fix): dense waves
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_fix_kernel(const uint4* __restrict__ prims, const PmRay* __restrict__ rays,
+                                                                PmHit* __restrict__ hits, uint8_t* __restrict__ occ,
+                                                                const uint4* __restrict__ defer_list,
+                                                                const uint32_t* __restrict__ defer_count,
+                                                                unsigned long long* __restrict__ counters) {
+    pmd::TravCounters tc = {0u, 0u, 0u, 0u, 0u};
+    auto fetch = [&](uint32_t i, pmd::Ray* ray) -> bool {
+        const float4* rp = reinterpret_cast<const float4*>(rays + i);
+        const float4 a = rp[0], b = rp[1];
+        ray->o = pmd::mk3(a.x, a.y, a.z); ray->tmax = a.w; ray->d = pmd::mk3(b.x, b.y, b.z);
+        return true;
+    };
+    auto load_t = [&](uint32_t i) -> float { return hits[i].t; };
+    auto commit = [&](uint32_t i, bool found, const pmd::HitRec& h) {
+        if (ANY) occ[i] = found ? 1 : 0;
+        else {
+            float4 o;
+            o.x = __uint_as_float(h.prim_id); o.y = h.t; o.z = h.u; o.w = h.v;
+            *reinterpret_cast<float4*>(hits + i) = o;
+        }
+    };
+    pmd::sphere_fix<ANY, COUNT>(prims, defer_list, defer_count, &tc, fetch, load_t, commit);
+    if (COUNT && tc.exact) atomicAdd(&counters[6], (unsigned long long)tc.exact);
 }
 
 int pm_gpu_build_tris(pm_ctx* c, int max_leaf, std::string& err);   // pm_gpu_build.hip
@@ -65,7 +128,7 @@ extern "C" int pm_create(int device_id, pm_ctx** out) {
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc(&c->d_work, PM_WORK_SLOTS * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&c->d_work, 2 * PM_WORK_SLOTS * sizeof(uint32_t)) != hipSuccess ||
         hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) {
         delete c;
         return PM_ERR_HIP;
@@ -83,6 +146,9 @@ extern "C" void pm_destroy(pm_ctx* c) {
     if (c->d_prims) (void)hipFree(c->d_prims);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_work) (void)hipFree(c->d_work);
+    if (c->d_defer) (void)hipFree(c->d_defer);
+    if (c->flat.tris) (void)hipFree((void*)c->flat.tris);
+    if (c->flat.units) (void)hipFree((void*)c->flat.units);
     if (c->d_stage_in) (void)hipFree(c->d_stage_in);
     if (c->d_stage_out) (void)hipFree(c->d_stage_out);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -216,6 +282,23 @@ extern "C" int pm_build_accel(pm_ctx* c, int split_method, int max_prims_in_node
         HIPCHK(c, hipMemcpy(c->d_nodes, c->accel.nodes.data(), nb, hipMemcpyHostToDevice));
         if (pb) HIPCHK(c, hipMemcpy(c->d_prims, c->accel.prims.data(), pb, hipMemcpyHostToDevice));
     }
+    // tiny scenes are swept flat (pm_device.hpp trace_flat); PBRT_MI355_FLAT_MAX=0 keeps the tree walk for them
+    if (c->flat.tris) { (void)hipFree((void*)c->flat.tris); }
+    if (c->flat.units) { (void)hipFree((void*)c->flat.units); }
+    c->flat = PmFlatScene{nullptr, nullptr, 0, 0, 0};
+    uint32_t flat_max = c->flat_max;
+    if (const char* e = std::getenv("PBRT_MI355_FLAT_MAX")) { int v = std::atoi(e); if (v >= 0 && v <= PM_FLAT_MAX_PRIMS) flat_max = (uint32_t)v; }
+    pm::build_flat_table(c->accel, flat_max);
+    if (c->device >= 0 && c->accel.flat_n[0] + c->accel.flat_n[1] + c->accel.flat_n[2] > 0) {
+        const size_t tb = std::max<size_t>(1, c->accel.flat_tris.size()) * sizeof(PmFlatTri);
+        const size_t ub = std::max<size_t>(1, c->accel.flat_units.size()) * sizeof(uint32_t);
+        PmFlatTri* dt = nullptr; uint32_t* du = nullptr;
+        HIPCHK(c, hipMalloc((void**)&dt, tb));
+        HIPCHK(c, hipMalloc((void**)&du, ub));
+        if (!c->accel.flat_tris.empty()) HIPCHK(c, hipMemcpy(dt, c->accel.flat_tris.data(), c->accel.flat_tris.size() * sizeof(PmFlatTri), hipMemcpyHostToDevice));
+        if (!c->accel.flat_units.empty()) HIPCHK(c, hipMemcpy(du, c->accel.flat_units.data(), c->accel.flat_units.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->flat = PmFlatScene{dt, du, c->accel.flat_n[0], c->accel.flat_n[1], c->accel.flat_n[2]};
+    }
     c->accel_valid = true;
     // refill threshold of the persistent traversal waves: walks through a tiny tree all have about the same (short)
     // length, so refilling early only multiplies the exact-test rounds; deep trees have long-tailed walks.
@@ -231,6 +314,8 @@ extern "C" int pm_build_accel(pm_ctx* c, int split_method, int max_prims_in_node
         info->node_buffer_bytes = nb; info->prim_buffer_bytes = pb;
         for (int k = 0; k < 3; ++k) { info->bounds[k] = c->accel.bounds.lo[k]; info->bounds[3 + k] = c->accel.bounds.hi[k]; }
         info->build_seconds = c->accel.build_seconds;
+        info->flat_prims = c->accel.flat_n[0] + c->accel.flat_n[1] + c->accel.flat_n[2];
+        info->reserved = 0;
     }
     return PM_OK;
 }
@@ -260,24 +345,43 @@ static int trace_impl(pm_ctx* c, const PmRay* rays, uint64_t n, void* out, size_
     }
     unsigned long long before[4];
     HIPCHK(c, hipMemcpyAsync(before, c->d_counters, sizeof(before), hipMemcpyDeviceToHost, c->stream));
-    // persistent waves pull ray indices from a work counter; one launch covers at most 2^30 rays
-    const uint64_t chunk = 1ull << 30;
+    // persistent waves pull ray indices from a work counter; one launch covers at most 2^30 rays (2^24 when the scene
+    // holds spheres: the deferred-sphere list has one 16-byte entry per ray of the launch)
+    const bool has_spheres = !c->scene.spheres.empty();
+    const uint64_t chunk = has_spheres ? (1ull << 24) : (1ull << 30);
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
-    if (n_chunks > PM_WORK_SLOTS) return fail(c, PM_ERR_INVALID, "trace: too many rays in one call");
-    HIPCHK(c, hipMemsetAsync(c->d_work, 0, PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
+    { int r = ensure_defer(c, (size_t)std::min<uint64_t>(chunk, n)); if (r) return r; }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     for (uint64_t k = 0; k < n_chunks; ++k) {
+        const uint32_t slot = (uint32_t)(k % PM_WORK_SLOTS);     // stream-ordered: a slot is free again when it comes round
+        if (slot == 0) HIPCHK(c, hipMemsetAsync(c->d_work, 0, 2 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
         const uint64_t b = k * chunk;
         const uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - b);
         const uint32_t grid = std::min<uint32_t>((m + TRACE_BLOCK - 1) / TRACE_BLOCK, (uint32_t)c->n_cu * PM_BLOCKS_PER_CU);
         PmHit* oh = ANY ? nullptr : (PmHit*)d_out + b;
         uint8_t* oo = ANY ? (uint8_t*)d_out + b : nullptr;
-        if (c->counting)
-            hipLaunchKernelGGL((trace_kernel<ANY, true>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_nodes, c->d_prims,
-                               d_rays + b, m, oh, oo, c->d_work + k, c->refill, c->d_counters);
-        else
-            hipLaunchKernelGGL((trace_kernel<ANY, false>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_nodes, c->d_prims,
-                               d_rays + b, m, oh, oo, c->d_work + k, c->refill, c->d_counters);
+        if (c->flat.tris) {
+            const uint32_t fgrid = std::min<uint32_t>((m + TRACE_BLOCK - 1) / TRACE_BLOCK, (uint32_t)c->n_cu * PM_FLAT_BLOCKS_PER_CU);
+            if (c->counting)
+                hipLaunchKernelGGL((trace_flat_kernel<ANY, true>), dim3(fgrid), dim3(TRACE_BLOCK), 0, c->stream, c->flat, c->d_prims,
+                                   d_rays + b, m, oh, oo, c->d_defer, c->d_work + PM_WORK_SLOTS + slot, c->d_counters);
+            else
+                hipLaunchKernelGGL((trace_flat_kernel<ANY, false>), dim3(fgrid), dim3(TRACE_BLOCK), 0, c->stream, c->flat, c->d_prims,
+                                   d_rays + b, m, oh, oo, c->d_defer, c->d_work + PM_WORK_SLOTS + slot, c->d_counters);
+        } else {
+            auto kernel = c->counting ? (has_spheres ? trace_kernel<ANY, true, true> : trace_kernel<ANY, true, false>)
+                                      : (has_spheres ? trace_kernel<ANY, false, true> : trace_kernel<ANY, false, false>);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_nodes, c->d_prims, d_rays + b, m, oh, oo,
+                               c->d_work + slot, c->refill, c->d_defer, c->d_counters);
+        }
+        if (has_spheres) {
+            if (c->counting)
+                hipLaunchKernelGGL((trace_fix_kernel<ANY, true>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_prims, d_rays + b,
+                                   oh, oo, c->d_defer, c->d_work + PM_WORK_SLOTS + slot, c->d_counters);
+            else
+                hipLaunchKernelGGL((trace_fix_kernel<ANY, false>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_prims, d_rays + b,
+                                   oh, oo, c->d_defer, c->d_work + PM_WORK_SLOTS + slot, c->d_counters);
+        }
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));

@@ -197,6 +197,12 @@ struct Collapser {
             std::memcpy(r.ofr, s.object_from_render, 48);
             r.radius = s.radius; r.z_min = s.z_min; r.z_max = s.z_max; r.phi_max = s.phi_max;
             r.prim_id = s.prim_id; r.flags = s.reverse_orientation ? 1u : 0u;
+            r.m_norm = 0.0f; r.t_norm = 0.0f;
+            for (int row = 0; row < 3; ++row) {
+                const float* m = s.object_from_render + 4 * row;
+                r.m_norm = std::fmax(r.m_norm, std::fabs(m[0]) + std::fabs(m[1]) + std::fabs(m[2]));
+                r.t_norm = std::fmax(r.t_norm, std::fabs(m[3]));
+            }
             size_t off = acc.prims.size(); acc.prims.resize(off + sizeof(r)); std::memcpy(&acc.prims[off], &r, sizeof(r));
         }
     }
@@ -328,6 +334,52 @@ int build_accel(const HostScene& sc, int max_leaf, Accel& acc, std::string& err)
     }
     acc.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return 0;
+}
+
+// Sweep order = node index, then slot, then record: the CPU checker (oracle/wide_walk.h) derives the same table from the
+// exported buffers.
+void build_flat_table(Accel& acc, uint32_t max_prims) {
+    acc.flat_tris.clear(); acc.flat_units.clear();
+    acc.flat_n[0] = acc.flat_n[1] = acc.flat_n[2] = 0;
+    size_t total = 0;
+    for (const PmWideNode& nd : acc.nodes)
+        for (int s = 0; s < 8; ++s) if (!((nd.imask >> s) & 1)) total += nd.meta[s] >> 5;
+    if (total == 0 || total > max_prims) return;
+    std::vector<uint32_t> sph, pat;
+    for (const PmWideNode& nd : acc.nodes) {
+        const uint32_t type = nd.prim_base >> 30, pbase = nd.prim_base & 0x3FFFFFFFu;
+        const uint32_t units = type == PM_PRIM_TRI ? PM_UNITS_TRI : (type == PM_PRIM_PATCH ? PM_UNITS_PATCH : PM_UNITS_SPHERE);
+        for (int s = 0; s < 8; ++s) {
+            if ((nd.imask >> s) & 1) continue;
+            const uint32_t cnt = nd.meta[s] >> 5, off = nd.meta[s] & 31u;
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const uint32_t unit = pbase + (off + j) * units;
+                if (type == PM_PRIM_SPHERE) sph.push_back(unit);
+                else if (type == PM_PRIM_PATCH) pat.push_back(unit);
+                else {
+                    const float* f = reinterpret_cast<const float*>(&acc.prims[(size_t)unit * 16]);
+                    PmFlatTri t{};
+                    float L = 0.0f;
+                    for (int k = 0; k < 3; ++k) {
+                        t.v0[k] = f[k];
+                        t.e1[k] = f[3 + k] - f[k];
+                        t.e2[k] = f[6 + k] - f[k];
+                        L = std::fmax(L, std::fmax(std::fabs(t.e1[k]), std::fabs(t.e2[k])));
+                    }
+                    t.n[0] = (float)((double)t.e1[1] * (double)t.e2[2] - (double)t.e1[2] * (double)t.e2[1]);
+                    t.n[1] = (float)((double)t.e1[2] * (double)t.e2[0] - (double)t.e1[0] * (double)t.e2[2]);
+                    t.n[2] = (float)((double)t.e1[0] * (double)t.e2[1] - (double)t.e1[1] * (double)t.e2[0]);
+                    t.L = L; t.unit = unit;
+                    t.c1 = std::fmax(std::fmax(std::fabs(t.v0[0]), std::fabs(t.v0[1])), std::fabs(t.v0[2])) + L;
+                    t.kll = (7.62939453125e-06f * L) * L;
+                    acc.flat_tris.push_back(t);
+                }
+            }
+        }
+    }
+    acc.flat_n[0] = (uint32_t)sph.size(); acc.flat_n[1] = (uint32_t)pat.size(); acc.flat_n[2] = (uint32_t)acc.flat_tris.size();
+    acc.flat_units = sph;
+    acc.flat_units.insert(acc.flat_units.end(), pat.begin(), pat.end());
 }
 
 }  // namespace pm

@@ -42,8 +42,15 @@ struct Accel {
     std::vector<uint8_t> prims;     // leaf records, 16-byte units
     Box bounds;
     double build_seconds = 0.0;
+    // flat table of a scene small enough to be swept without a tree (pm_layout.h PmFlatTri; empty otherwise):
+    // flat_n[0] sphere record units, then flat_n[1] patch record units (uint32 each), in flat_units; flat_n[2] triangles
+    std::vector<PmFlatTri> flat_tris;
+    std::vector<uint32_t> flat_units;
+    uint32_t flat_n[3] = {0, 0, 0};
 };
 
 int build_accel(const HostScene& sc, int max_leaf, Accel& acc, std::string& err);
+// fills acc.flat_* from acc.nodes / acc.prims when the tree references at most max_prims primitives (clears them otherwise)
+void build_flat_table(Accel& acc, uint32_t max_prims);
 
 }  // namespace pm

@@ -18,7 +18,21 @@ struct RenderState;   // pm_render.hip
 #ifndef PM_BLOCKS_PER_CU
 #define PM_BLOCKS_PER_CU 8      // persistent traversal grids: 8 blocks x 2 waves per CU = 4 waves per SIMD
 #endif
-#ifdef PM_WAVES_PER_EU
+#ifndef PM_FLAT_BLOCKS_PER_CU
+#define PM_FLAT_BLOCKS_PER_CU 16    // flat-sweep grids (grid-stride over 64-item groups): small kernels, high occupancy
+#endif
+#ifndef PM_FLAT_WAVES_PER_EU
+#define PM_FLAT_WAVES_PER_EU 5      // measured (scripts/ab_flat.sh): 5 waves/SIMD beat the compiler's choice (4); 6 spills
+#endif
+#if PM_FLAT_WAVES_PER_EU > 0
+#define PM_FLAT_ATTR __attribute__((amdgpu_waves_per_eu(PM_FLAT_WAVES_PER_EU, PM_FLAT_WAVES_PER_EU)))
+#else
+#define PM_FLAT_ATTR
+#endif
+#ifndef PM_WAVES_PER_EU
+#define PM_WAVES_PER_EU 4           // tree-walk kernels: capping VGPRs for 4 waves/SIMD (the compiler picks 3) measured +8 %
+#endif                              // on the C4-shaped path workload, +10 % on incoherent C3 rays (scripts/ab_bvh.sh)
+#if PM_WAVES_PER_EU > 0
 #define PM_TRAV_ATTR __attribute__((amdgpu_waves_per_eu(PM_WAVES_PER_EU, PM_WAVES_PER_EU)))
 #else
 #define PM_TRAV_ATTR
@@ -36,7 +50,12 @@ struct pm_ctx {
     PmWideNode* d_nodes = nullptr;
     uint4* d_prims = nullptr;
     unsigned long long* d_counters = nullptr;   // [1] nodes [2] prims [3] overflow [4] shadow nodes [5] shadow prims [6] exact [7] fallback
-    uint32_t* d_work = nullptr;                 // PM_WORK_SLOTS work-item counters of the persistent traversal kernels
+    uint32_t* d_work = nullptr;                 // PM_WORK_SLOTS work-item counters of the persistent traversal kernels,
+                                                // then PM_WORK_SLOTS entry counts of the deferred-sphere list (same slot index)
+    PmFlatScene flat = {nullptr, nullptr, 0, 0, 0};   // device flat table; n_* all zero = walk the tree
+    uint32_t flat_max = PM_FLAT_MAX_PRIMS;      // scenes of at most this many primitives are swept flat (0: never)
+    uint4* d_defer = nullptr;                   // deferred (work item, sphere, sphere) entries of ONE traversal launch
+    size_t defer_cap = 0;                       // ... in entries; stays null for scenes without spheres
     int n_cu = 256;
     uint32_t refill = 24;                       // idle lanes that trigger a wave refill (chosen in pm_build_accel)
     bool counting = false;
@@ -61,6 +80,17 @@ static inline bool is_device_ptr(const void* p) {
     hipError_t e = hipPointerGetAttributes(&a, p);
     if (e != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+static inline int ensure(pm_ctx* c, void** buf, size_t* cap, size_t need);
+// room for one deferred-sphere entry per work item of a traversal launch (only scenes that hold spheres defer)
+static inline int ensure_defer(pm_ctx* c, size_t items) {
+    // + what the waves of the largest traversal grid can leave unused of their reservations (pm_device.hpp DeferWriter)
+    items += (size_t)c->n_cu * PM_FLAT_BLOCKS_PER_CU * (TRACE_BLOCK / 64) * 256;
+    if (c->scene.spheres.empty() || c->defer_cap >= items) return PM_OK;
+    if (c->d_defer) { HIPCHK(c, hipFree(c->d_defer)); c->d_defer = nullptr; c->defer_cap = 0; }
+    HIPCHK(c, hipMalloc((void**)&c->d_defer, items * sizeof(uint4)));
+    c->defer_cap = items;
+    return PM_OK;
 }
 static inline int ensure(pm_ctx* c, void** buf, size_t* cap, size_t need) {
     if (*cap >= need) return PM_OK;

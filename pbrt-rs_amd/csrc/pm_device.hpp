@@ -252,31 +252,135 @@ PMD f3 fcross(f3 a, f3 b) {
     return mk3(__fmaf_rn(a.y, b.z, -(a.z * b.y)), __fmaf_rn(a.z, b.x, -(a.x * b.z)), __fmaf_rn(a.x, b.y, -(a.y * b.x)));
 }
 PMD float fdot(f3 a, f3 b) { return __fmaf_rn(a.z, b.z, __fmaf_rn(a.y, b.y, a.x * b.x)); }
-PMD int tri_prefilter(f3 ro, f3 rd, float R, float D, f3 v0, f3 v1, f3 v2, float tcull, float* t_hi) {
+PMD int tri_classify(float det, float uu, float vv, float tt, float L, float S, float R, float D, float tcull, float* t_hi,
+                     float* t_lo);
+PMD int tri_prefilter(f3 ro, f3 rd, float R, float D, f3 v0, f3 v1, f3 v2, float tcull, float* t_hi, float* t_lo) {
     const f3 e1 = v1 - v0, e2 = v2 - v0, sv = ro - v0;
     const f3 pv = fcross(rd, e2);
-    float det = fdot(e1, pv), uu = fdot(sv, pv);
+    const float det = fdot(e1, pv), uu = fdot(sv, pv);
     const f3 qv = fcross(sv, e1);
-    float vv = fdot(rd, qv), tt = fdot(e2, qv);
+    const float vv = fdot(rd, qv), tt = fdot(e2, qv);
     const float L = fmaxf(maxc3(abs3(e1)), maxc3(abs3(e2))), S = maxc3(abs3(sv));
+    return tri_classify(det, uu, vv, tt, L, S, R, D, tcull, t_hi, t_lo);
+}
+// The flat sweep's version, from a flat-table entry (pm_layout.h PmFlatTri: e1, e2, n = e1 x e2, L, c1, kll precomputed):
+//   uu = sv.(rd x e2) = e2.(sv x rd)   vv = rd.(sv x e1) = -e1.(sv x rd)   det = e1.(rd x e2) = -rd.n   tt = e2.(sv x e1) = sv.n
+// 21 multiply-adds instead of 33; the magnitudes of the terms (hence the error bounds) are those of tri_prefilter, with
+// S = max|ro - v0| bounded by R + max|v0| (so Sx = 2R + c1: one add).  No division: the culling distance is kept as a
+// fraction cn / cd (cd > 0), "t beyond tcull" and "t_hi below tcull" are cross-multiplied, and a certain hit replaces the
+// fraction by its own ((tt + ttau) * 1.00001, det - tb).  The candidate's lower bound is the fraction (ln, ld).
+struct FlatCull { float cn, cd; };
+PMD int tri_prefilter_flat(f3 ro, f3 rd, float KD, float R2, f3 v0, f3 e1, f3 e2, f3 n, float L, float c1, float kll,
+                           float epsb_ray, FlatCull* cull, bool lower, float* ln, float* ld) {
+    const f3 sv = ro - v0;
+    const f3 m = fcross(sv, rd);
+    float uu = fdot(e2, m), vv = -fdot(e1, m), det = -fdot(rd, n), tt = fdot(sv, n);
+    if (det < 0.0f) { det = -det; uu = -uu; vv = -vv; tt = -tt; }
+    const float Sx = R2 + c1;
+    const float tb = (KD * L) * Sx;
+    const float ttau = kll * Sx;
+    const float dp = det + tb;
+    const bool reject = (uu < -tb) | (vv < -tb) | (uu + vv > dp + tb) | (tt < -ttau) | ((tt - ttau) * cull->cd > cull->cn * dp);
+    if (reject) return 0;
+    *ln = 0.0f; *ld = 1.0f;
+    if ((uu > tb) & (vv > tb) & (uu + vv < (det - tb) - tb) & (det > 2.0f * tb) & (tt > ttau)) {
+        const float hn = (tt + ttau) * 1.00001f, hd = det - tb;
+        const float lo = (tt - ttau) * 0.99999f;
+        // epsb >= the exact test's gamma(10) * sum of max-abs: 8e-7 * (5R + D + 4(S + L)) with S <= R + max|v0|
+        const float epsb = __fmaf_rn(3.2e-6f, c1, epsb_ray);
+        if ((lo > epsb * dp) & (hn * cull->cd < cull->cn * hd)) {
+            if (lower) { cull->cn = hn; cull->cd = hd; }
+            *ln = lo; *ld = dp;
+            return 2;
+        }
+    }
+    return 1;
+}
+PMD int tri_classify(float det, float uu, float vv, float tt, float L, float S, float R, float D, float tcull, float* t_hi,
+                     float* t_lo) {
     if (det < 0.0f) { det = -det; uu = -uu; vv = -vv; tt = -tt; }
     // error bounds.  The pre-filter itself works on differences (errors relative to L, S), but the exact test it must agree
     // with rounds absolute coordinates (errors relative to |ro| + |p| <= 2R + S + L), so the bounds carry Sx = S + R + L.
     const float Sx = S + R + L;
     const float tb = PM_PRE_K * D * L * Sx;            // bound for det, uu, vv
     const float ttau = PM_PRE_K * L * L * Sx;          // bound for tt
-    if (uu < -tb || vv < -tb || uu + vv > det + 2.0f * tb) return 0;
-    if (tt < -ttau) return 0;
-    if (tt > __fmaf_rn(tcull, det + tb, ttau)) return 0;
+    // one branch for the common outcome (bitwise |: all five comparisons are cheaper than four nested branches)
+    const bool reject = (uu < -tb) | (vv < -tb) | (uu + vv > det + 2.0f * tb) | (tt < -ttau) |
+                        (tt > __fmaf_rn(tcull, det + tb, ttau));
+    if (reject) return 0;
     // certain hit: inside by more than the error bounds; t bracketed by [ (tt - ttau)/(det + tb), (tt + ttau)/(det - tb) ]
-    if (uu > tb && vv > tb && uu + vv < det - 2.0f * tb && det > 2.0f * tb && tt > ttau) {
+    *t_lo = 0.0f;
+    if ((uu > tb) & (vv > tb) & (uu + vv < det - 2.0f * tb) & (det > 2.0f * tb) & (tt > ttau)) {
         const float epsb = 8e-7f * (5.0f * R + D + 4.0f * (S + L));     // >= the exact test's gamma(10) * sum of max-abs
         const float th = ((tt + ttau) / (det - tb)) * 1.00001f;
         const float tl = ((tt - ttau) / (det + tb)) * 0.99999f;
-        if (tl > epsb && th < tcull) { *t_hi = th; return 2; }
+        if (tl > epsb && th < tcull) { *t_hi = th; *t_lo = tl; return 2; }
     }
     return 1;
 }
+
+// ---- float pre-filter for spheres: false = the exact (interval) test cannot accept this sphere with t <= tcull.
+// The interval test costs ~1500 instructions and a wave pays for it as soon as ONE lane runs it, so spheres that pass are
+// not tested inside the walk: the (ray, sphere) pair goes to a global list and a second, dense kernel runs the exact
+// tests (sphere_fix below).  Plain f32 in object space with forward error bounds; m_norm / t_norm (from the record) bound
+// the rounding of the transform exactly as Transform * Point3fi does (gamma(3) * sum of |terms|, core/transform.rs).  The
+// interval test itself rejects whenever its discriminant interval reaches below zero, so rejecting where the real
+// discriminant is negative by more than the bound can never remove a hit.  The CPU walker repeats these operations.
+#define PM_SPH_EPS 4.76837158203125e-07f      /* 8 * 2^-24 */
+PMD bool sphere_prefilter(f3 ro, f3 rd, float R, float D, const float* m, float radius, float m_norm, float t_norm, float tcull) {
+    const f3 o = mk3(__fmaf_rn(m[0], ro.x, __fmaf_rn(m[1], ro.y, __fmaf_rn(m[2], ro.z, m[3]))),
+                     __fmaf_rn(m[4], ro.x, __fmaf_rn(m[5], ro.y, __fmaf_rn(m[6], ro.z, m[7]))),
+                     __fmaf_rn(m[8], ro.x, __fmaf_rn(m[9], ro.y, __fmaf_rn(m[10], ro.z, m[11]))));
+    const f3 d = mk3(__fmaf_rn(m[0], rd.x, __fmaf_rn(m[1], rd.y, m[2] * rd.z)),
+                     __fmaf_rn(m[4], rd.x, __fmaf_rn(m[5], rd.y, m[6] * rd.z)),
+                     __fmaf_rn(m[8], rd.x, __fmaf_rn(m[9], rd.y, m[10] * rd.z)));
+    const float a = fdot(d, d), b = fdot(o, d), oo = fdot(o, o), rr = radius * radius;
+    const float c = oo - rr;
+    const float Om = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)), Dm = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    const float eo = PM_SPH_EPS * __fmaf_rn(m_norm, R, t_norm);       // per-component error of o
+    const float ed = PM_SPH_EPS * (m_norm * D);                       // ... of d
+    const float db = 3.0f * __fmaf_rn(Om, ed, Dm * eo);
+    const float dc = 6.0f * (Om * eo), da = 6.0f * (Dm * ed);
+    const float base = PM_SPH_EPS * __fmaf_rn(a, oo + rr, b * b);
+    const float disc = __fmaf_rn(b, b, -(a * c));
+    const float E = 4.0f * (__fmaf_rn(2.0f * fabsf(b), db, __fmaf_rn(a, dc, fabsf(c) * da)) + base);
+    if (disc < -E) return false;
+    const float cl = c - 2.0f * __fmaf_rn(PM_SPH_EPS, oo + rr, dc);   // origin outside the sphere by more than the bound
+    if (cl > 0.0f) {
+        if (b > db) return false;                                     // moving away: both roots are negative
+        const float den = (db - b) + sqrtf(fmaxf(disc, 0.0f) + E) * 1.000001f;
+        if (den > 0.0f && (cl / den) * 0.99999f > tcull) return false;   // the near root lies beyond tcull
+    }
+    return true;
+}
+
+// Appending to the deferred-sphere list.  One atomic per wave per append on a single counter serialises (measured: ~5 ns
+// each, as much time as the whole sweep of the C2 scene), so a wave reserves PM_DEFER_CHUNK entries at a time and fills
+// them itself; what is left of a reservation is padded with invalid entries (item == ~0) that the second pass skips.
+// The list therefore needs room for items + waves * PM_DEFER_CHUNK entries (pm_ctx.h ensure_defer).  All members are
+// wave-uniform: call push / finish from wave-uniform control flow only.
+#define PM_DEFER_CHUNK 256u
+struct DeferWriter {
+    uint4* list; uint32_t* count; uint32_t next, end;
+    PMD void pad(uint32_t lane) {
+        for (uint32_t i = next + lane; i < end; i += 64u) list[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u);
+        next = end;
+    }
+    PMD void push(bool defer, uint32_t lane, uint32_t item, uint32_t s0, uint32_t s1) {
+        const unsigned long long dm = __ballot(defer);
+        const uint32_t n = (uint32_t)__popcll(dm);
+        if (n == 0u) return;
+        if (next + n > end) {
+            pad(lane);
+            uint32_t base = 0;
+            if (lane == 0u) base = atomicAdd(count, PM_DEFER_CHUNK);
+            next = __shfl(base, 0);
+            end = next + PM_DEFER_CHUNK;
+        }
+        if (defer) list[next + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = make_uint4(item, s0, s1, 0u);
+        next += n;
+    }
+};
 
 #define PM_CAND_MAX 4
 PMD float safe_rcp_dir(float d) { return fabsf(d) < 1e-18f ? copysignf(1e18f, d) : 1.0f / d; }
@@ -297,13 +401,16 @@ PMD float safe_rcp_dir(float d) { return fabsf(d) < 1e-18f ? copysignf(1e18f, d)
 // assumed (it would take an error-analysis failure; counted in fallback), the ray is walked again with immediate exact
 // tests, so results are exact regardless.
 //
+// SPH: the scene holds spheres; those that pass sphere_prefilter are deferred to defer_list (kernels for scenes without
+// spheres are compiled without any of that: it costs registers, i.e. occupancy).
 //   fetch(i, &ray) -> bool   load work item i (false: nothing to trace for it)
 //   commit(i, found, hit)    store the result of work item i
 // `lds` is this lane's column of the per-block LDS stack (entry e at lds[e * stride]); `cand` this lane's column of the
 // candidate queue.
-template <bool ANY, bool COUNT, class FetchFn, class CommitFn>
+template <bool ANY, bool COUNT, bool SPH, class FetchFn, class CommitFn>
 PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __restrict__ prims, uint32_t n_items,
                           uint32_t* __restrict__ work_counter, uint32_t refill, uint2* lds, uint32_t* cand, int stride,
+                          uint4* __restrict__ defer_list, uint32_t* __restrict__ defer_count,
                           TravCounters* ctr, FetchFn fetch, CommitFn commit) {
     const float widen = 1.0f + 2.0f * gamma_n(3);
     const uint32_t lane = threadIdx.x & 63u;
@@ -318,6 +425,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
     float R = 0.f, D = 0.f, tmax = 0.f, tcull = 0.f;
     bool sure = false, found = false, exact_mode = false;
     uint32_t qn = 0;
+    uint32_t sph0 = 0xFFFFFFFFu, sph1 = 0xFFFFFFFFu;      // spheres that passed the pre-filter (deferred to sphere_fix)
     int sp = 0;
     uint2 cur = make_uint2(0u, 0u);
     HitRec hit; hit.prim_id = 0xFFFFFFFFu; hit.t = 0.f; hit.u = 0.f; hit.v = 0.f;
@@ -325,6 +433,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
 
     auto start_walk = [&]() {
         tmax = ray.tmax; tcull = ray.tmax; sure = false; found = false; qn = 0; sp = 0; steps = 0;
+        sph0 = 0xFFFFFFFFu; sph1 = 0xFFFFFFFFu;
         hit.prim_id = 0xFFFFFFFFu; hit.t = ray.tmax; hit.u = 0.0f; hit.v = 0.0f;
         cur = make_uint2(0u, (1u << 8) | perm8(1u, oct));     // pseudo group holding only the root
         active = true;
@@ -335,14 +444,17 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
     uint32_t chunk = n_items / (gridDim.x * (blockDim.x >> 6) * 4u);
     chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : (chunk & ~63u));
     uint32_t wnext = 0, wend = 0;
+    DeferWriter dw; dw.list = defer_list; dw.count = defer_count; dw.next = 0u; dw.end = 0u;
 
     for (;;) {
         const uint32_t n_idle = (uint32_t)__popcll(__ballot(!active));
         if (n_idle == 64u || ((more || wnext < wend) && n_idle >= refill)) {
             // ---- lanes whose walk has ended: exact tests of the queued triangles, in the order they were met
+            bool defer = false;
             if (finished) {
                 for (uint32_t qi = 0; qi < PM_CAND_MAX; ++qi) {
-                    if (qi >= qn || (ANY && found)) continue;
+                    // a certain hit whose t bracket starts beyond the final tcull lies behind another certain hit
+                    if (qi >= qn || (ANY && found) || __uint_as_float(cand[(PM_CAND_MAX + qi) * stride]) > tcull) continue;
                     const uint4* r = prims + cand[qi * stride];
                     const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
                     const f3 v0 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
@@ -357,9 +469,14 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                 finished = false;
                 // did the exact tests confirm what culling assumed?
                 const bool confirmed = !sure || (found && (ANY || hit.t <= tcull));
-                if (confirmed || exact_mode) commit(item, found, hit);
-                else { exact_mode = true; if (COUNT) ctr->fallback++; start_walk(); }
+                if (confirmed || exact_mode) {
+                    // closest hit: commit what the walk found, sphere_fix improves it; any hit: an occluded ray needs no
+                    // sphere test, an unoccluded one is committed by sphere_fix
+                    defer = SPH && sph0 != 0xFFFFFFFFu && !(ANY && found);
+                    if (!ANY || !defer) commit(item, found, hit);
+                } else { exact_mode = true; if (COUNT) ctr->fallback++; start_walk(); }
             }
+            if (SPH) dw.push(defer, lane, item, sph0, sph1);      // wave-uniform control flow here
             // ---- idle lanes fetch the next items
             if (wnext >= wend && more) {
                 uint32_t base = 0;
@@ -398,7 +515,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                 const uint32_t nw = (uint32_t)__popcll(want);
                 wnext = wnext + nw < wend ? wnext + nw : wend;
             }
-            if (!__any(active) && !more && wnext >= wend) break;
+            if (!__any(active) && !more && wnext >= wend) { if (SPH) dw.pad(lane); break; }
         }
         if (active) {
             // ---- one node step (the pop of an exhausted group is merged into it)
@@ -486,6 +603,13 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                             m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
                             const float radius = __uint_as_float(r3.x), zmin = __uint_as_float(r3.y), zmax = __uint_as_float(r3.z),
                                         phimax = __uint_as_float(r3.w);
+                            if (SPH && !exact_mode) {
+                                if (!sphere_prefilter(ray.o, ray.d, R, D, m, radius, __uint_as_float(r4.z), __uint_as_float(r4.w), tcull))
+                                    continue;
+                                const uint32_t unit = pbase + (off + j) * PM_UNITS_SPHERE;
+                                if (sph0 == 0xFFFFFFFFu) { sph0 = unit; continue; }
+                                if (sph1 == 0xFFFFFFFFu) { sph1 = unit; continue; }
+                            }                       // a third sphere for the same ray is tested at once
                             if (COUNT) ctr->exact++;
                             SphereHit sh;
                             if (intersect_sphere(ray.o, ray.d, tmax, m, radius, zmin, zmax, phimax, &sh)) {
@@ -507,12 +631,15 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                             const f3 p01 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
                             bool immediate = true;
                             if (is_tri && !exact_mode) {
-                                float th;
-                                const int cls = tri_prefilter(ray.o, ray.d, R, D, p00, p10, p01, tcull, &th);
+                                float th, tl;
+                                const int cls = tri_prefilter(ray.o, ray.d, R, D, p00, p10, p01, tcull, &th, &tl);
                                 if (cls == 0) immediate = false;
                                 else {
                                     if (cls == 2) { sure = true; if (!ANY) tcull = th; }
-                                    if (qn < PM_CAND_MAX) { cand[qn * stride] = unit; ++qn; immediate = false; }
+                                    if (qn < PM_CAND_MAX) {
+                                        cand[qn * stride] = unit; cand[(PM_CAND_MAX + qn) * stride] = __float_as_uint(tl);
+                                        ++qn; immediate = false;
+                                    }
                                 }
                             }
                             if (immediate) {    // patches; triangles when the queue is full or in the fallback walk
@@ -537,6 +664,244 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                 cur = make_uint2(n1.x, (imask << 8) | perm8(hits & imask, oct));
             }
         }
+    }
+}
+
+// ---- scenes of at most PM_FLAT_MAX_PRIMS primitives: no tree.  Every wave takes 64 consecutive work items and sweeps the
+// whole flat table (pm_layout.h) in lock step: the records are wave-uniform (scalar loads), nothing diverges but the
+// bookkeeping, and there are no node steps.  Spheres go through sphere_prefilter and are deferred, patches are tested at
+// once (reference arithmetic), triangles go through tri_prefilter_flat into the candidate queue exactly as in
+// trace_persistent; then the exact round, the confirmation and (never seen) the exact re-sweep.
+using FlatScene = PmFlatScene;
+// Read-only scene data addressed wave-uniformly: loads through the constant address space become scalar loads (one per
+// wave, into SGPRs) instead of 64 identical vector loads.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef const uint32_t __attribute__((address_space(4))) * cuint_p;
+struct cuint4_p {
+    const u32x4_t __attribute__((address_space(4))) * p;
+    PMD uint4 operator[](int i) const { const u32x4_t v = p[i]; return make_uint4(v.x, v.y, v.z, v.w); }
+};
+PMD cuint4_p as_uniform(const uint4* p) { cuint4_p r; r.p = (const u32x4_t __attribute__((address_space(4))) *)p; return r; }
+PMD cuint_p as_uniform(const uint32_t* p) { return (cuint_p)p; }
+
+template <bool ANY, bool COUNT, class FetchFn, class CommitFn>
+PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_items, uint32_t* cand, int stride,
+                    uint4* __restrict__ defer_list, uint32_t* __restrict__ defer_count, TravCounters* ctr, FetchFn fetch,
+                    CommitFn commit) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    DeferWriter dw; dw.list = defer_list; dw.count = defer_count; dw.next = 0u; dw.end = 0u;
+    for (uint32_t base = wave * 64u; base < n_items; base += n_waves * 64u) {
+        const uint32_t item = base + lane;
+        Ray ray; ray.o = mk3(0.f, 0.f, 0.f); ray.d = mk3(0.f, 0.f, 1.f); ray.tmax = 0.f;
+        bool live = item < n_items && fetch(item, &ray);
+        if (live) {
+            const float dsum = fabsf(ray.d.x) + fabsf(ray.d.y) + fabsf(ray.d.z);
+            const float osum = fabsf(ray.o.x) + fabsf(ray.o.y) + fabsf(ray.o.z);
+            if (!(dsum > 0.0f && dsum < INFINITY && osum < INFINITY)) {     // degenerate ray: a miss (see trace_persistent)
+                HitRec miss; miss.prim_id = 0xFFFFFFFFu; miss.t = ray.tmax; miss.u = 0.0f; miss.v = 0.0f;
+                commit(item, false, miss);
+                live = false;
+            }
+        }
+        const float R = maxc3(abs3(ray.o)), D = maxc3(abs3(ray.d));
+        float tmax = ray.tmax, tcull = ray.tmax;
+        bool sure = false, found = false;
+        uint32_t qn = 0, sph0 = 0xFFFFFFFFu, sph1 = 0xFFFFFFFFu;
+        HitRec hit; hit.prim_id = 0xFFFFFFFFu; hit.t = ray.tmax; hit.u = 0.0f; hit.v = 0.0f;
+
+        auto test_sphere_now = [&](uint32_t unit) {
+            const uint4* r = prims + unit;
+            float m[12];
+            const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+            m[0] = __uint_as_float(r0.x); m[1] = __uint_as_float(r0.y); m[2] = __uint_as_float(r0.z); m[3] = __uint_as_float(r0.w);
+            m[4] = __uint_as_float(r1.x); m[5] = __uint_as_float(r1.y); m[6] = __uint_as_float(r1.z); m[7] = __uint_as_float(r1.w);
+            m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
+            const float radius = __uint_as_float(r3.x), zmin = __uint_as_float(r3.y), zmax = __uint_as_float(r3.z),
+                        phimax = __uint_as_float(r3.w);
+            if (COUNT) ctr->exact++;
+            SphereHit sh;
+            if (intersect_sphere(ray.o, ray.d, tmax, m, radius, zmin, zmax, phimax, &sh)) {
+                tmax = sh.t; tcull = fminf(tcull, sh.t); found = true; hit.prim_id = r4.x; hit.t = sh.t;
+                const float th0 = acosf(fminf(fmaxf(zmin / radius, -1.0f), 1.0f));
+                const float th1 = acosf(fminf(fmaxf(zmax / radius, -1.0f), 1.0f));
+                const float th = acosf(fminf(fmaxf(sh.p_obj.z / radius, -1.0f), 1.0f));
+                hit.u = sh.phi / phimax; hit.v = (th - th0) / (th1 - th0);
+            }
+        };
+        auto test_patch_now = [&](uint32_t unit, bool is_tri) {
+            const uint4* r = prims + unit;
+            const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
+            const f3 p00 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
+            const f3 p10 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
+            const f3 p01 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
+            f3 p11 = p01;
+            uint32_t id = r2.y;
+            if (!is_tri) {
+                const uint4 r3 = r[3];
+                p11 = mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
+                id = r3.x;
+            }
+            if (COUNT) ctr->exact++;
+            float t, u, v;
+            if (intersect_patch(ray.o, ray.d, tmax, p00, p10, p01, p11, &t, &u, &v)) {
+                tmax = t; found = true; hit.prim_id = id; hit.t = t; hit.u = u; hit.v = v;
+                return true;
+            }
+            return false;
+        };
+
+        // ---- spheres: pre-filter, deferred (a third sphere for the same ray is tested at once)
+        for (uint32_t i = 0; i < fs.n_sphere; ++i) {
+            const uint32_t unit = as_uniform(fs.units)[i];
+            if (live && !(ANY && (found || sure))) {
+                if (COUNT) ctr->prims++;
+                bool now = defer_list == nullptr;
+                if (!now) {
+                    const cuint4_p r = as_uniform(prims + unit);
+                    float m[12];
+                    const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+                    m[0] = __uint_as_float(r0.x); m[1] = __uint_as_float(r0.y); m[2] = __uint_as_float(r0.z); m[3] = __uint_as_float(r0.w);
+                    m[4] = __uint_as_float(r1.x); m[5] = __uint_as_float(r1.y); m[6] = __uint_as_float(r1.z); m[7] = __uint_as_float(r1.w);
+                    m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
+                    if (sphere_prefilter(ray.o, ray.d, R, D, m, __uint_as_float(r3.x), __uint_as_float(r4.z), __uint_as_float(r4.w), tcull)) {
+                        if (sph0 == 0xFFFFFFFFu) sph0 = unit;
+                        else if (sph1 == 0xFFFFFFFFu) sph1 = unit;
+                        else now = true;
+                    }
+                }
+                if (now) test_sphere_now(unit);
+            }
+        }
+        // ---- patches: reference arithmetic at once
+        for (uint32_t i = 0; i < fs.n_patch; ++i) {
+            const uint32_t unit = as_uniform(fs.units)[fs.n_sphere + i];
+            if (live && !(ANY && (found || sure))) {
+                if (COUNT) ctr->prims++;
+                if (test_patch_now(unit, false)) tcull = fminf(tcull, hit.t);
+            }
+        }
+        // ---- triangles: pre-filter, candidates queued for the exact round.  The culling distance becomes a fraction.
+        FlatCull cull; cull.cn = tcull; cull.cd = 1.0f;
+        const float KD = PM_PRE_K * D, R2 = 2.0f * R, epsb_ray = 8e-7f * __fmaf_rn(9.0f, R, D);
+        for (uint32_t i = 0; i < fs.n_tri; ++i) {
+            if (ANY && !__any(live && !(found || sure))) break;
+            const cuint4_p e = as_uniform(reinterpret_cast<const uint4*>(fs.tris + i));
+            const uint4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3];
+            if (live && !(ANY && (found || sure))) {
+                if (COUNT) ctr->prims++;
+                float ln, ld;
+                const int cls = tri_prefilter_flat(ray.o, ray.d, KD, R2,
+                                                   mk3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)),
+                                                   mk3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)),
+                                                   mk3(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z)),
+                                                   mk3(__uint_as_float(q3.x), __uint_as_float(q3.y), __uint_as_float(q3.z)),
+                                                   __uint_as_float(q0.w), __uint_as_float(q2.w), __uint_as_float(q3.w), epsb_ray,
+                                                   &cull, !ANY, &ln, &ld);
+                if (cls != 0) {
+                    if (cls == 2) sure = true;
+                    if (qn < PM_CAND_MAX) {
+                        cand[qn * stride] = q1.w;
+                        cand[(PM_CAND_MAX + qn) * stride] = __float_as_uint(ln);
+                        cand[(2 * PM_CAND_MAX + qn) * stride] = __float_as_uint(ld);
+                        ++qn;
+                    } else (void)test_patch_now(q1.w, true);    // queue full: exact test at once (does not lower the culling distance)
+                }
+            }
+        }
+        // ---- exact round: the queued triangles, in the order they were met, minus the certain hits whose t bracket starts
+        // beyond the final culling distance (they lie behind another certain hit); compacted first so that the wave makes
+        // as many trips as its busiest lane has survivors
+        {
+            uint32_t m = 0;
+            for (uint32_t qi = 0; qi < PM_CAND_MAX; ++qi) {
+                if (qi >= qn) continue;
+                const float ln = __uint_as_float(cand[(PM_CAND_MAX + qi) * stride]), ld = __uint_as_float(cand[(2 * PM_CAND_MAX + qi) * stride]);
+                if (!(ln * cull.cd > cull.cn * ld)) { cand[m * stride] = cand[qi * stride]; ++m; }
+            }
+            qn = m;
+        }
+        for (uint32_t qi = 0; qi < PM_CAND_MAX; ++qi) {
+            if (!__any(live && qi < qn && !(ANY && found))) break;
+            if (live && qi < qn && !(ANY && found)) {
+                const uint4* r = prims + cand[qi * stride];
+                const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
+                const f3 v0 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
+                const f3 v1 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
+                const f3 v2 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
+                if (COUNT) ctr->exact++;
+                float t, u, v;
+                if (intersect_tri_exact(ray.o, ray.d, tmax, v0, v1, v2, &t, &u, &v)) {
+                    tmax = t; found = true; hit.prim_id = r2.y; hit.t = t; hit.u = u; hit.v = v;
+                }
+            }
+        }
+        // ---- did the exact tests confirm what culling assumed?  If not: everything again, exactly (counted; never seen)
+        const bool redo = live && sure && !(found && (ANY || !(hit.t * cull.cd > cull.cn)));
+        if (__any(redo)) {
+            if (redo) {
+                if (COUNT) ctr->fallback++;
+                tmax = ray.tmax; found = false; sph0 = 0xFFFFFFFFu; sph1 = 0xFFFFFFFFu;
+                hit.prim_id = 0xFFFFFFFFu; hit.t = ray.tmax; hit.u = 0.0f; hit.v = 0.0f;
+            }
+            for (uint32_t i = 0; i < fs.n_sphere; ++i) {
+                const uint32_t unit = fs.units[i];
+                if (redo && !(ANY && found)) { if (COUNT) ctr->prims++; test_sphere_now(unit); }
+            }
+            for (uint32_t i = 0; i < fs.n_patch; ++i) {
+                const uint32_t unit = fs.units[fs.n_sphere + i];
+                if (redo && !(ANY && found)) { if (COUNT) ctr->prims++; (void)test_patch_now(unit, false); }
+            }
+            for (uint32_t i = 0; i < fs.n_tri; ++i) {
+                const uint32_t unit = fs.tris[i].unit;
+                if (redo && !(ANY && found)) { if (COUNT) ctr->prims++; (void)test_patch_now(unit, true); }
+            }
+        }
+        // ---- commit; rays with deferred spheres go to the second pass (see trace_persistent)
+        const bool defer = live && sph0 != 0xFFFFFFFFu && !(ANY && found);
+        if (live && (!ANY || !defer)) commit(item, found, hit);
+        if (defer_list != nullptr) dw.push(defer, lane, item, sph0, sph1);
+    }
+    if (defer_list != nullptr) dw.pad(lane);
+}
+
+// Second pass over the (work item, sphere, sphere) entries that trace_persistent deferred: every lane runs the exact
+// interval test, so the waves of this pass are dense.  Closest hit: the entry's ray already has its best non-deferred hit
+// committed; load_t(i) returns that t and commit(i, true, hit) overwrites it when a sphere is nearer.  Any hit: the ray was
+// not occluded by anything else and has not been committed; commit(i, occluded, .) finishes it.
+template <bool ANY, bool COUNT, class FetchFn, class LoadTFn, class CommitFn>
+PMD void sphere_fix(const uint4* __restrict__ prims, const uint4* __restrict__ defer_list, const uint32_t* __restrict__ defer_count,
+                    TravCounters* ctr, FetchFn fetch, LoadTFn load_t, CommitFn commit) {
+    const uint32_t n = *defer_count;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const uint4 ent = defer_list[e];
+        Ray ray;
+        if (ent.x == 0xFFFFFFFFu || !fetch(ent.x, &ray)) continue;      // padding of a wave's reservation
+        float tmax = ANY ? ray.tmax : load_t(ent.x);
+        bool found = false;
+        HitRec hit; hit.prim_id = 0xFFFFFFFFu; hit.t = tmax; hit.u = 0.0f; hit.v = 0.0f;
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t unit = k ? ent.z : ent.y;
+            if (unit == 0xFFFFFFFFu || (ANY && found)) continue;
+            const uint4* r = prims + unit;
+            float m[12];
+            const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+            m[0] = __uint_as_float(r0.x); m[1] = __uint_as_float(r0.y); m[2] = __uint_as_float(r0.z); m[3] = __uint_as_float(r0.w);
+            m[4] = __uint_as_float(r1.x); m[5] = __uint_as_float(r1.y); m[6] = __uint_as_float(r1.z); m[7] = __uint_as_float(r1.w);
+            m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
+            const float radius = __uint_as_float(r3.x), zmin = __uint_as_float(r3.y), zmax = __uint_as_float(r3.z),
+                        phimax = __uint_as_float(r3.w);
+            if (COUNT) ctr->exact++;
+            SphereHit sh;
+            if (intersect_sphere(ray.o, ray.d, tmax, m, radius, zmin, zmax, phimax, &sh)) {
+                tmax = sh.t; found = true; hit.prim_id = r4.x; hit.t = sh.t;
+                const float th0 = acosf(fminf(fmaxf(zmin / radius, -1.0f), 1.0f));
+                const float th1 = acosf(fminf(fmaxf(zmax / radius, -1.0f), 1.0f));
+                const float th = acosf(fminf(fmaxf(sh.p_obj.z / radius, -1.0f), 1.0f));
+                hit.u = sh.phi / phimax; hit.v = (th - th0) / (th1 - th0);
+            }
+        }
+        if (ANY || found) commit(ent.x, found, hit);
     }
 }
 

@@ -41,9 +41,27 @@ struct alignas(16) PmPatchRecord {    // 64 B
 struct alignas(16) PmSphereRecord {   // 80 B; object_from_render rows 0..2 (affine: row 3 == 0,0,0,1)
     float ofr[12];
     float radius, z_min, z_max, phi_max;
-    uint32_t prim_id; uint32_t flags; uint32_t pad[2];
+    uint32_t prim_id; uint32_t flags;
+    float m_norm;     // max over rows of |m_r0| + |m_r1| + |m_r2|   } error scales of the float pre-filter
+    float t_norm;     // max over rows of |m_r3|                     } (pm_device.hpp sphere_prefilter)
 };
 static_assert(sizeof(PmTriRecord) == 48 && sizeof(PmPatchRecord) == 64 && sizeof(PmSphereRecord) == 80, "record sizes");
+
+// Scenes of at most PM_FLAT_MAX_PRIMS primitives are not walked at all: every wave sweeps ALL primitives in lock step
+// (wave-uniform records, no divergence, no node steps), which beats any tree of that size on 64-lane SIMT hardware.
+// One 64-byte entry per triangle, derived from its record: e1 = v1 - v0, e2 = v2 - v0 (f32), n = e1 x e2 (f64 products,
+// rounded once), L = max |component| of e1, e2; c1 = max |component| of v0 + L and kll = (K * L) * L (K = 128 * 2^-24)
+// are the triangle's share of the pre-filter's error bounds; `unit` locates the 48-byte record for the exact test.
+#define PM_FLAT_MAX_PRIMS 64
+struct alignas(16) PmFlatTri {
+    float v0[3]; float L;
+    float e1[3]; uint32_t unit;
+    float e2[3]; float c1;
+    float n[3];  float kll;
+};
+static_assert(sizeof(PmFlatTri) == 64, "flat triangle entry is 64 bytes");
+// kernel argument: device pointers; units = n_sphere sphere record units, then n_patch patch record units
+struct PmFlatScene { const PmFlatTri* tris; const uint32_t* units; uint32_t n_sphere, n_patch, n_tri; };
 
 #define PM_MAX_LEAF 4
 #define PM_LDS_STACK 12      // per-lane entries kept in LDS

@@ -14,6 +14,14 @@
 #include "pm_shade.hpp"
 
 #define RB 256          // block size of the non-traversal kernels
+#ifndef PM_SHADE_WAVES_PER_EU
+#define PM_SHADE_WAVES_PER_EU 0
+#endif
+#if PM_SHADE_WAVES_PER_EU > 0
+#define PM_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(PM_SHADE_WAVES_PER_EU, PM_SHADE_WAVES_PER_EU)))
+#else
+#define PM_SHADE_ATTR
+#endif
 #define TB TRACE_BLOCK  // block size of the traversal kernels
 
 using namespace pmd;
@@ -89,12 +97,12 @@ __global__ __launch_bounds__(RB) void raygen_kernel(RenderConst rc, SceneArrays 
 }
 
 // ------------------------------------------------------------------------------------------ traversal
-template <bool COUNT>
+template <bool COUNT, bool SPH>
 __global__ __launch_bounds__(TB) PM_TRAV_ATTR void closest_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
                                                      const uint32_t* __restrict__ count, uint32_t* __restrict__ work, uint32_t refill,
-                                                     unsigned long long* __restrict__ counters) {
+                                                     uint4* __restrict__ defer_list, unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
-    __shared__ uint32_t cand[PM_CAND_MAX * TB];
+    __shared__ uint32_t cand[2 * PM_CAND_MAX * TB];     // units, then t lower bounds
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
         const uint32_t slot = queue[i];
@@ -107,18 +115,20 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR void closest_kernel(SceneArrays sc
     auto commit = [&](uint32_t i, bool found, const HitRec& h) {
         pa.hit[queue[i]] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
     };
-    trace_persistent<false, COUNT>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB, &tc, fetch, commit);
+    trace_persistent<false, COUNT, SPH>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB,
+                                   defer_list, work + PM_WORK_SLOTS, &tc, fetch, commit);
     if (COUNT) {
         atomicAdd(&counters[1], (unsigned long long)tc.nodes); atomicAdd(&counters[2], (unsigned long long)tc.prims);
         atomicAdd(&counters[6], (unsigned long long)tc.exact); if (tc.fallback) atomicAdd(&counters[7], (unsigned long long)tc.fallback);
     }
     if (tc.overflow) atomicAdd(&counters[3], 1ull);
 }
-template <bool COUNT>
+template <bool COUNT, bool SPH>
 __global__ __launch_bounds__(TB) PM_TRAV_ATTR void shadow_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ count,
-                                                    uint32_t* __restrict__ work, uint32_t refill, unsigned long long* __restrict__ counters) {
+                                                    uint32_t* __restrict__ work, uint32_t refill, uint4* __restrict__ defer_list,
+                                                    unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
-    __shared__ uint32_t cand[PM_CAND_MAX * TB];
+    __shared__ uint32_t cand[2 * PM_CAND_MAX * TB];     // units, then t lower bounds
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
         const uint32_t slot = pa.shq[i];
@@ -135,12 +145,107 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR void shadow_kernel(SceneArrays sc,
             pa.L[slot] = L;
         }
     };
-    trace_persistent<true, COUNT>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB, &tc, fetch, commit);
+    trace_persistent<true, COUNT, SPH>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB,
+                                  defer_list, work + PM_WORK_SLOTS, &tc, fetch, commit);
     if (COUNT) {
         atomicAdd(&counters[4], (unsigned long long)tc.nodes); atomicAdd(&counters[5], (unsigned long long)tc.prims);
         atomicAdd(&counters[6], (unsigned long long)tc.exact); if (tc.fallback) atomicAdd(&counters[7], (unsigned long long)tc.fallback);
     }
     if (tc.overflow) atomicAdd(&counters[3], 1ull);
+}
+// flat-sweep variants for scenes of at most PM_FLAT_MAX_PRIMS primitives (pm_device.hpp trace_flat)
+template <bool COUNT>
+__global__ __launch_bounds__(TB) PM_FLAT_ATTR void closest_flat_kernel(PmFlatScene fs, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
+                                                          const uint32_t* __restrict__ count, uint4* __restrict__ defer_list,
+                                                          uint32_t* __restrict__ defer_count, unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t cand[3 * PM_CAND_MAX * TB];     // units, then the lower bounds of t as fractions (numerators, denominators)
+    TravCounters tc = {0u, 0u, 0u, 0u, 0u};
+    auto fetch = [&](uint32_t i, Ray* ray) -> bool {
+        const uint32_t slot = queue[i];
+        const float4 o = pa.ray_o[slot];
+        if (o.w != 0.0f) return false;          // dead slot (raygen)
+        const float4 d = pa.ray_d[slot];
+        ray->o = mk3(o.x, o.y, o.z); ray->d = mk3(d.x, d.y, d.z); ray->tmax = INFINITY;
+        return true;
+    };
+    auto commit = [&](uint32_t i, bool found, const HitRec& h) {
+        pa.hit[queue[i]] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
+    };
+    trace_flat<false, COUNT>(fs, sc.prims, *count, cand + threadIdx.x, TB, defer_list, defer_count, &tc, fetch, commit);
+    if (COUNT) {
+        atomicAdd(&counters[2], (unsigned long long)tc.prims); atomicAdd(&counters[6], (unsigned long long)tc.exact);
+        if (tc.fallback) atomicAdd(&counters[7], (unsigned long long)tc.fallback);
+    }
+}
+template <bool COUNT>
+__global__ __launch_bounds__(TB) PM_FLAT_ATTR void shadow_flat_kernel(PmFlatScene fs, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ count,
+                                                         uint4* __restrict__ defer_list, uint32_t* __restrict__ defer_count,
+                                                         unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t cand[3 * PM_CAND_MAX * TB];     // units, then the lower bounds of t as fractions (numerators, denominators)
+    TravCounters tc = {0u, 0u, 0u, 0u, 0u};
+    auto fetch = [&](uint32_t i, Ray* ray) -> bool {
+        const uint32_t slot = pa.shq[i];
+        const float4 o = pa.sh_o[slot], d = pa.sh_d[slot];
+        ray->o = mk3(o.x, o.y, o.z); ray->d = mk3(d.x, d.y, d.z); ray->tmax = o.w;
+        return true;
+    };
+    auto commit = [&](uint32_t i, bool occluded, const HitRec&) {
+        if (!occluded) {
+            const uint32_t slot = pa.shq[i];
+            float4 L = pa.L[slot];
+            const float4 c = pa.sh_L[slot];
+            L.x += c.x; L.y += c.y; L.z += c.z; L.w += c.w;
+            pa.L[slot] = L;
+        }
+    };
+    trace_flat<true, COUNT>(fs, sc.prims, *count, cand + threadIdx.x, TB, defer_list, defer_count, &tc, fetch, commit);
+    if (COUNT) {
+        atomicAdd(&counters[5], (unsigned long long)tc.prims); atomicAdd(&counters[6], (unsigned long long)tc.exact);
+        if (tc.fallback) atomicAdd(&counters[7], (unsigned long long)tc.fallback);
+    }
+}
+// exact tests of the spheres the kernels above deferred (pm_device.hpp sphere_fix), with the same fetch / commit
+template <bool COUNT>
+__global__ __launch_bounds__(TB) void closest_fix_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
+                                                         const uint4* __restrict__ defer_list, const uint32_t* __restrict__ defer_count,
+                                                         unsigned long long* __restrict__ counters) {
+    TravCounters tc = {0u, 0u, 0u, 0u, 0u};
+    auto fetch = [&](uint32_t i, Ray* ray) -> bool {
+        const uint32_t slot = queue[i];
+        const float4 o = pa.ray_o[slot], d = pa.ray_d[slot];
+        ray->o = mk3(o.x, o.y, o.z); ray->d = mk3(d.x, d.y, d.z); ray->tmax = INFINITY;
+        return true;
+    };
+    auto load_t = [&](uint32_t i) -> float { return pa.hit[queue[i]].y; };
+    auto commit = [&](uint32_t i, bool found, const HitRec& h) {
+        pa.hit[queue[i]] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
+    };
+    sphere_fix<false, COUNT>(sc.prims, defer_list, defer_count, &tc, fetch, load_t, commit);
+    if (COUNT && tc.exact) atomicAdd(&counters[6], (unsigned long long)tc.exact);
+}
+template <bool COUNT>
+__global__ __launch_bounds__(TB) void shadow_fix_kernel(SceneArrays sc, PathArrays pa, const uint4* __restrict__ defer_list,
+                                                        const uint32_t* __restrict__ defer_count,
+                                                        unsigned long long* __restrict__ counters) {
+    TravCounters tc = {0u, 0u, 0u, 0u, 0u};
+    auto fetch = [&](uint32_t i, Ray* ray) -> bool {
+        const uint32_t slot = pa.shq[i];
+        const float4 o = pa.sh_o[slot], d = pa.sh_d[slot];
+        ray->o = mk3(o.x, o.y, o.z); ray->d = mk3(d.x, d.y, d.z); ray->tmax = o.w;
+        return true;
+    };
+    auto load_t = [&](uint32_t) -> float { return 0.0f; };
+    auto commit = [&](uint32_t i, bool occluded, const HitRec&) {
+        if (!occluded) {
+            const uint32_t slot = pa.shq[i];
+            float4 L = pa.L[slot];
+            const float4 c = pa.sh_L[slot];
+            L.x += c.x; L.y += c.y; L.z += c.z; L.w += c.w;
+            pa.L[slot] = L;
+        }
+    };
+    sphere_fix<true, COUNT>(sc.prims, defer_list, defer_count, &tc, fetch, load_t, commit);
+    if (COUNT && tc.exact) atomicAdd(&counters[6], (unsigned long long)tc.exact);
 }
 
 // ------------------------------------------------------------------------------------------ shade
@@ -195,7 +300,7 @@ __device__ __forceinline__ Bsdf make_bsdf(const SceneArrays& sc, const PathArray
     return bsdf;
 }
 
-__global__ __launch_bounds__(RB) void shade_kernel(RenderConst rc, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ qin,
+__global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ qin,
                                                    const uint32_t* __restrict__ count_in, uint32_t* __restrict__ qout,
                                                    uint32_t* __restrict__ count_out, uint32_t* __restrict__ shadow_count) {
     __shared__ uint32_t lds_a[RB / 64 + 1], lds_b[RB / 64 + 1];
@@ -757,6 +862,8 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     if (max_paths > 0x7FFFFFFFull) return fail(c, PM_ERR_INVALID, "pm_render: window too large for one pass");
     const bool random_walk = p->integrator == PM_INTEGRATOR_RANDOM_WALK;
     if ((rcode = ensure_paths(c, r, max_paths, p->max_depth, random_walk))) return rcode;
+    if ((rcode = ensure_defer(c, max_paths))) return rcode;
+    const bool has_spheres = !c->scene.spheres.empty();
 
     RenderConst rc{};
     std::memcpy(rc.cfr, r->cam.camera_from_raster, 64); std::memcpy(rc.rfc, r->cam.render_from_camera, 48);
@@ -791,30 +898,52 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
         rc.s_base = sb; rc.s_count = std::min(s_per_pass, s1 - sb);
         const uint32_t npaths = (uint32_t)(npix_pad * (size_t)rc.s_count);
         HIPCHK(c, hipMemsetAsync(pa.counts, 0, 2 * (size_t)nb * 4, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_work, 0, PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_work, 0, 2 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
         int wslot = 0;      // one work counter per traversal launch (re-zeroed when the slots run out)
         const dim3 gr((npaths + RB - 1) / RB);
         const dim3 gt(std::min<uint32_t>((npaths + TB - 1) / TB, (uint32_t)c->n_cu * PM_BLOCKS_PER_CU));
+        const dim3 gf(std::min<uint32_t>((npaths + TB - 1) / TB, (uint32_t)c->n_cu * PM_FLAT_BLOCKS_PER_CU));
+        const bool flat = c->flat.tris != nullptr;
         mark(0);
         hipLaunchKernelGGL(raygen_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, npaths);
         uint32_t *qin = pa.q0, *qout = pa.q1;
         for (int b = 0; b <= p->max_depth; ++b) {
             uint32_t* cnt_in = pa.counts + b; uint32_t* cnt_out = pa.counts + b + 1; uint32_t* cnt_sh = pa.counts + nb + b;
             if (wslot + 2 > PM_WORK_SLOTS) {   // stream-ordered: every earlier traversal kernel has finished with its counter
-                HIPCHK(c, hipMemsetAsync(c->d_work, 0, PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
+                HIPCHK(c, hipMemsetAsync(c->d_work, 0, 2 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
                 wslot = 0;
             }
             mark(1);
-            if (c->counting) hipLaunchKernelGGL(closest_kernel<true>, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_work + wslot, c->refill, c->d_counters);
-            else hipLaunchKernelGGL(closest_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_work + wslot, c->refill, c->d_counters);
+            if (flat) {
+                if (c->counting) hipLaunchKernelGGL(closest_flat_kernel<true>, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, qin, cnt_in, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_counters);
+                else hipLaunchKernelGGL(closest_flat_kernel<false>, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, qin, cnt_in, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_counters);
+            } else {
+                auto kernel = c->counting ? (has_spheres ? closest_kernel<true, true> : closest_kernel<true, false>)
+                                          : (has_spheres ? closest_kernel<false, true> : closest_kernel<false, false>);
+                hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_work + wslot, c->refill, c->d_defer, c->d_counters);
+            }
+            if (has_spheres) {     // dense exact tests of the deferred spheres (timed with the closest-hit class)
+                if (c->counting) hipLaunchKernelGGL(closest_fix_kernel<true>, gt, dim3(TB), 0, c->stream, sa, pa, qin, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_counters);
+                else hipLaunchKernelGGL(closest_fix_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, qin, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_counters);
+            }
             ++wslot;
             mark(2);
             if (random_walk) hipLaunchKernelGGL(shade_rw_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, qin, cnt_in, qout, cnt_out);
             else hipLaunchKernelGGL(shade_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, qin, cnt_in, qout, cnt_out, cnt_sh);
             if (!random_walk && p->sample_lights && b < p->max_depth) {
                 mark(3);
-                if (c->counting) hipLaunchKernelGGL(shadow_kernel<true>, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_work + wslot, c->refill, c->d_counters);
-                else hipLaunchKernelGGL(shadow_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_work + wslot, c->refill, c->d_counters);
+                if (flat) {
+                    if (c->counting) hipLaunchKernelGGL(shadow_flat_kernel<true>, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, cnt_sh, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_counters);
+                    else hipLaunchKernelGGL(shadow_flat_kernel<false>, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, cnt_sh, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_counters);
+                } else {
+                    auto kernel = c->counting ? (has_spheres ? shadow_kernel<true, true> : shadow_kernel<true, false>)
+                                              : (has_spheres ? shadow_kernel<false, true> : shadow_kernel<false, false>);
+                    hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_work + wslot, c->refill, c->d_defer, c->d_counters);
+                }
+                if (has_spheres) {
+                    if (c->counting) hipLaunchKernelGGL(shadow_fix_kernel<true>, gt, dim3(TB), 0, c->stream, sa, pa, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_counters);
+                    else hipLaunchKernelGGL(shadow_fix_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_counters);
+                }
                 ++wslot;
             }
             std::swap(qin, qout);

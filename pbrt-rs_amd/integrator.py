@@ -16,9 +16,10 @@ from .aggregate import GpuAggregate
 
 class WavefrontIntegrator:
     def __init__(self, max_depth, sample_lights, sample_bsdf, scene, spp, seed=0, device_id=0,
-                 integrator=PM_INTEGRATOR_SIMPLE_PATH, split_method=_capi.PM_SPLIT_SAH):
+                 integrator=PM_INTEGRATOR_SIMPLE_PATH, split_method=_capi.PM_SPLIT_SAH, max_prims_in_node=4):
         self.scene = scene
-        self.aggregate = GpuAggregate(scene.prims, device_id=device_id, split_method=split_method)
+        self.aggregate = GpuAggregate(scene.prims, max_prims_in_node=max_prims_in_node, device_id=device_id,
+                                      split_method=split_method)
         self._lib = self.aggregate._lib
         self._h = self.aggregate._h
         ck = self.aggregate._check

@@ -1,0 +1,18 @@
+#!/bin/bash
+# GPU box: tree-walk workloads (C3 trace, C4-shaped path) with several builds of the library in one call
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+OUT=gpurun_out/ab_bvh.log
+: > $OUT
+for lib in "" "$@"; do
+  echo "== lib=${lib:-current}" >> $OUT
+  PBRT_MI355_LIB=${lib:+$R/$lib} timeout -k 10 200 python -u bench.py --workload trace --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('C3 primary %.0f Mrays/s (%.2f ms) shadow %.0f incoherent %.0f' % (d['value'], d['roofline']['kernel_ms'], d['shadow_any_hit']['value'], d['incoherent_closest_hit']['value']))" >> $OUT 2>&1 || exit 1
+  PBRT_MI355_LIB=${lib:+$R/$lib} timeout -k 10 300 python -u bench.py --workload c4 --blobs 4096 --res 1920 --spp 16 --steps 2 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('C4-small %.1f Msamples/s  kernel_ms %s' % (d['value']/1e6, {k: round(v,1) for k,v in d['config']['kernel_ms'].items()}))" >> $OUT 2>&1 || exit 1
+done

@@ -1,0 +1,90 @@
+"""Scenes of at most 64 primitives are swept flat by the kernels (no tree walk; pm_device.hpp trace_flat).  CPU check of
+that logic through its mirror in oracle/wide_walk.h: the flat sweep must return the reference traversal's hits bit for
+bit, also for rays aimed exactly at edges and vertices, where the float pre-filter has to stay undecided."""
+import numpy as np
+import pytest
+
+
+def _edge_rays(pm, pos, idx, rng, n):
+    """rays through points ON triangle edges / vertices / just inside / just outside, from random origins"""
+    tri = pos[np.asarray(idx).reshape(-1, 3)]
+    k = rng.integers(0, len(tri), n)
+    a, b, c = tri[k, 0], tri[k, 1], tri[k, 2]
+    kind = rng.integers(0, 4, n)
+    s = rng.random((n, 1)).astype(np.float32)
+    w = rng.dirichlet([1, 1, 1], n).astype(np.float32)
+    target = np.where((kind == 0)[:, None], a + (b - a) * s, 0)                       # on edge ab
+    target = np.where((kind == 1)[:, None], a, target)                              # vertex
+    target = np.where((kind == 2)[:, None], a * w[:, :1] + b * w[:, 1:2] + c * w[:, 2:], target)     # interior
+    out = a + (b - a) * s + (a - c) * np.float32(1e-6)
+    target = np.where((kind == 3)[:, None], out, target)                            # a hair outside edge ab
+    o = (target + rng.normal(size=(n, 3)) * rng.uniform(0.3, 30.0, (n, 1))).astype(np.float32)
+    rays = np.zeros(n, dtype=pm.RAY_DTYPE)
+    rays["o"] = o
+    rays["d"] = ((target - o) * rng.uniform(0.2, 3.0, (n, 1))).astype(np.float32)
+    rays["tmax"] = np.where(rng.random(n) < 0.3, rng.uniform(0.2, 1.5, n), np.inf).astype(np.float32)
+    return rays
+
+
+def _scene(pm, seed):
+    rng = np.random.default_rng(seed)
+    nt = int(rng.integers(8, 40))
+    pos = (rng.normal(size=(nt * 3, 3)) * rng.uniform(0.2, 3.0, (nt * 3, 1))).astype(np.float32)
+    idx = np.arange(nt * 3, dtype=np.uint32).reshape(-1, 3)
+    prims = [pm.TriangleMesh(pos, idx)]
+    quad = np.array([[-3, -3, -2.5], [3, -3, -2.5], [-3, 3, -2.0], [3, 3, -3.0]], np.float32)
+    prims.append(pm.BilinearPatchMesh(quad, [[0, 1, 2, 3]]))
+    for _ in range(int(rng.integers(1, 5))):
+        m = np.eye(4, dtype=np.float32)
+        m[:3, 3] = rng.uniform(-2, 2, 3)
+        mi = np.eye(4, dtype=np.float32)
+        mi[:3, 3] = -m[:3, 3]
+        r = float(rng.uniform(0.3, 1.0))
+        prims.append(pm.Sphere(r, -r, r, 360.0, m, mi))
+    return prims, pos, idx, rng
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_flat_sweep_equals_reference(pm, ora, seed):
+    import helpers
+    prims, pos, idx, rng = _scene(pm, seed)
+    agg = pm.GpuAggregate(prims, device_id=-1)
+    assert agg.info.flat_prims == agg.info.n_prims <= 64
+
+    class SD:
+        pass
+    sd = SD()
+    sd.prims = prims
+    sc = helpers.oracle_scene_from(sd, ora)
+    rays = np.concatenate([_edge_rays(pm, pos, idx, rng, 150_000), pm.scenes.incoherent_rays(50_000, seed=seed, radius=6.0)])
+    ref, _ = sc.intersect(rays)
+    nb, pb = agg.node_buffer(), agg.prim_buffer()
+    flat, fc = ora.wide_trace(nb, pb, rays, flat=True)
+    tree, tc = ora.wide_trace(nb, pb, rays, flat=False)
+    assert 0.3 < (ref["prim_id"] != 0xFFFFFFFF).mean() < 0.99
+    for name, got in (("flat", flat), ("tree", tree)):
+        same = got["prim_id"] == ref["prim_id"]
+        assert (~same).sum() <= 4, name                         # exact-t ties (shared edges / vertices)
+        assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32)), name
+        assert np.array_equal(got["u"][same].view(np.uint32), ref["u"][same].view(np.uint32)), name
+    assert fc["nodes_visited"] == 0 and fc["fallback_walks"] == 0 and tc["fallback_walks"] == 0
+    assert fc["prims_tested"] == len(rays) * agg.info.n_prims - _degenerate(rays) * agg.info.n_prims
+    occ, oc = ora.wide_trace(nb, pb, rays, any_hit=True, flat=True)
+    occ_ref, _ = sc.intersect_p(rays)
+    assert np.array_equal(occ.astype(bool), occ_ref.astype(bool))
+    assert oc["prims_tested"] < fc["prims_tested"]
+
+
+def _degenerate(rays):
+    d = np.abs(rays["d"]).sum(axis=1)
+    return int((~((d > 0) & np.isfinite(d) & np.isfinite(np.abs(rays["o"]).sum(axis=1)))).sum())
+
+
+def test_flat_threshold_and_switch(pm, monkeypatch):
+    pos, idx = pm.scenes.blob_mesh(1, 64, seed=3)
+    assert pm.GpuAggregate([pm.TriangleMesh(pos, idx)], device_id=-1).info.flat_prims == 64
+    pos, idx = pm.scenes.blob_mesh(1, 65, seed=3)
+    assert pm.GpuAggregate([pm.TriangleMesh(pos, idx)], device_id=-1).info.flat_prims == 0
+    monkeypatch.setenv("PBRT_MI355_FLAT_MAX", "0")
+    pos, idx = pm.scenes.blob_mesh(1, 16, seed=3)
+    assert pm.GpuAggregate([pm.TriangleMesh(pos, idx)], device_id=-1).info.flat_prims == 0

@@ -1,0 +1,71 @@
+"""GPU parity of the flat sweep (scenes of at most 64 primitives, pm_device.hpp trace_flat) through the C ABI:
+hits against the reference traversal, counters against the CPU mirror of the sweep, and the same scene walked
+through its tree (PBRT_MI355_FLAT_MAX=0) for comparison."""
+import numpy as np
+import pytest
+
+from test_flat_cpu import _edge_rays, _scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_flat_and_tree_kernels_equal_reference(pm, ora, monkeypatch, seed):
+    import helpers
+    prims, pos, idx, rng = _scene(pm, seed)
+
+    class SD:
+        pass
+    sd = SD()
+    sd.prims = prims
+    sc = helpers.oracle_scene_from(sd, ora)
+    rays = np.concatenate([_edge_rays(pm, pos, idx, rng, 400_000), pm.scenes.incoherent_rays(200_000, seed=seed, radius=6.0)])
+    rays["d"][:3] = [[0, 0, 0], [np.nan, 1, 0], [np.inf, 0, 0]]      # degenerate rays: misses
+    ref, _ = sc.intersect(rays)
+    ref_a, _ = sc.intersect_p(rays)
+    for flat_max in ("64", "0"):
+        monkeypatch.setenv("PBRT_MI355_FLAT_MAX", flat_max)
+        agg = pm.GpuAggregate(prims)
+        is_flat = agg.info.flat_prims != 0
+        assert is_flat == (flat_max == "64")
+        agg.set_counting(True)
+        agg.reset_counters()
+        gpu = agg.intersect(rays)
+        c = agg.counters()
+        cpu, cw = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays, flat=is_flat)
+        # the kernel and its CPU mirror: identical, ties included (same order of exact tests)
+        assert np.array_equal(gpu["prim_id"], cpu["prim_id"])
+        assert np.array_equal(gpu["t"].view(np.uint32), cpu["t"].view(np.uint32))
+        for k in ("nodes_visited", "prims_tested", "exact_tests", "fallback_walks"):
+            assert c[k] == cw[k], (flat_max, k, c, cw)
+        assert c["fallback_walks"] == 0 and (c["nodes_visited"] == 0) == is_flat
+        # the reference traversal: bit-identical t, ids up to exact-t ties
+        assert np.array_equal(gpu["t"].view(np.uint32), ref["t"].view(np.uint32))
+        assert (gpu["prim_id"] != ref["prim_id"]).sum() <= 4
+        agg.reset_counters()
+        occ = agg.intersect_p(rays)
+        ca = agg.counters()
+        occ_cpu, cwa = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays, any_hit=True, flat=is_flat)
+        assert np.array_equal(occ.astype(bool), ref_a.astype(bool))
+        for k in ("nodes_visited", "prims_tested", "exact_tests", "fallback_walks"):
+            assert ca[k] == cwa[k], (flat_max, "any", k, ca, cwa)
+        agg.set_counting(False)
+        del agg
+
+
+def test_cornell_film_flat_equals_tree(pm, monkeypatch):
+    """The wavefront render of the C2 scene is the same film whether rays sweep the 35 primitives or walk their tree."""
+    sd = pm.scenes.cornell_scene((96, 96))
+    films = []
+    for flat_max in ("64", "0"):
+        monkeypatch.setenv("PBRT_MI355_FLAT_MAX", flat_max)
+        integ = pm.WavefrontIntegrator(5, True, True, sd, 4, seed=3)
+        assert (integ.aggregate.info.flat_prims != 0) == (flat_max == "64")
+        integ.clear()
+        st = integ.render()
+        films.append((integ.film().copy(), st))
+        del integ
+    (fa, sa), (fb, sb) = films
+    assert sa["closest_rays"] == sb["closest_rays"] and sa["shadow_rays"] == sb["shadow_rays"]
+    differing = (fa != fb).any(axis=-1).mean()
+    assert differing < 1e-3, differing          # exact-t ties along shared edges may pick the other triangle

@@ -70,7 +70,7 @@ def test_device_built_tree(pm, ora):
     occ_ref, _ = sc.intersect_p(rays)
     assert np.array_equal(agg.intersect_p(rays), occ_ref)
     # the CPU walk of the very same (device-built) tree reproduces the kernel's counters
-    _, cw = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays)
+    _, cw = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays, flat=agg.info.flat_prims != 0)
     assert (c["nodes_visited"], c["prims_tested"], c["exact_tests"]) == (cw["nodes_visited"], cw["prims_tested"], cw["exact_tests"])
     # a linear BVH is coarser than binned SAH, but not absurdly so
     sah.set_counting(True)

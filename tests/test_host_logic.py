@@ -18,7 +18,7 @@ def test_wide_tree_walk_equals_reference_traversal(pm, ora):
     agg = _agg(pm, [pm.TriangleMesh(pos, idx)])
     assert agg.info.n_prims == len(idx) and agg.info.node_bytes == 80
     rays = np.concatenate([pm.scenes.primary_rays(64, 64), pm.scenes.incoherent_rays(4096, seed=9)])
-    wide, wc = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays)
+    wide, wc = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays, flat=agg.info.flat_prims != 0)
     sc = ora.Scene()
     sc.add_triangle_mesh(pos, idx)
     sc.build(ora.SPLIT_SAH, 4)
@@ -29,7 +29,7 @@ def test_wide_tree_walk_equals_reference_traversal(pm, ora):
     assert np.array_equal(wide["v"].view(np.uint32), ref["v"].view(np.uint32))
     assert (wide["prim_id"] != ref["prim_id"]).sum() <= 1          # exact-t tie class only
     assert wc["nodes_visited"] < rc["nodes_visited"]
-    occ, _ = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays, any_hit=True)
+    occ, _ = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays, any_hit=True, flat=agg.info.flat_prims != 0)
     assert np.array_equal(occ.astype(bool), ref["prim_id"] != 0xFFFFFFFF)
 
 
@@ -83,7 +83,7 @@ def test_mixed_types_join_node(pm, ora):
     sd = pm.scenes.main_rs_scene((16, 16))
     agg = _agg(pm, sd.prims)
     rays = pm.scenes.incoherent_rays(4096, seed=1, radius=8.0)
-    wide, _ = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays)
+    wide, _ = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays, flat=agg.info.flat_prims != 0)
     sc = helpers.oracle_scene_from(sd, ora)
     ref, _ = sc.intersect(rays)
     assert np.array_equal(wide["prim_id"], ref["prim_id"])

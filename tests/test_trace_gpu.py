@@ -89,7 +89,7 @@ def test_counters_match_cpu_walk_of_same_tree(pm, ora):
     agg.reset_counters()
     gpu = agg.intersect(rays)
     c = agg.counters()
-    cpu, cw = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays)
+    cpu, cw = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays, flat=agg.info.flat_prims != 0)
     assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32))
     assert c["rays"] == len(rays)
     assert c["nodes_visited"] == cw["nodes_visited"]
@@ -100,7 +100,7 @@ def test_counters_match_cpu_walk_of_same_tree(pm, ora):
     agg.reset_counters()
     sh = pm.scenes.shadow_rays(rays, gpu)
     ga = agg.intersect_p(sh)
-    ca, cwa = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), sh, any_hit=True)
+    ca, cwa = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), sh, any_hit=True, flat=agg.info.flat_prims != 0)
     c = agg.counters()
     assert np.array_equal(ga, ca)
     assert (c["nodes_visited"], c["prims_tested"], c["exact_tests"]) == (cwa["nodes_visited"], cwa["prims_tested"], cwa["exact_tests"])
