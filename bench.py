@@ -32,21 +32,28 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 KERNEL_NAMES = ["raygen_kernel", "closest_kernel", "shade_kernel", "shadow_kernel", "accumulate_kernel"]
 
 
-def pmc_traffic(kernel_prefix, tag):
-    """HBM bytes per launch of `kernel_prefix` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/rNN/pmc_summary_<tag>.json, made by scripts/profile_gpu.sh + scripts/summarize_pmc.py): FETCH_SIZE doubled
-    for wide loads as MI355X_MICROARCH.md prescribes, plus WRITE_SIZE.  None when no summary is committed."""
+def pmc_traffic(kernel_regex, tag):
+    """HBM bytes per launch of the kernel whose name matches `kernel_regex`, from the committed rocprofv3 --pmc passes of
+    this same command (profiles/rNN/pmc_summary_<tag>.json, made by scripts/profile_gpu.sh + scripts/summarize_pmc.py):
+    FETCH_SIZE doubled for wide loads as MI355X_MICROARCH.md prescribes, plus WRITE_SIZE.  None when no summary is
+    committed.  The newest round's summary that holds the kernel wins."""
     import glob
+    import re
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_summary_{tag}.json")), reverse=True):
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
         for name, v in d.items():
-            if name.startswith(kernel_prefix) and "true" not in name.split("<")[-1] and "fetch_bytes_x2_wide_loads" in v \
-                    and "write_bytes" in v:
+            if re.search(kernel_regex, name) and "fetch_bytes_x2_wide_loads" in v and "write_bytes" in v:
                 return (v["fetch_bytes_x2_wide_loads"] + v["write_bytes"]) / max(1, v["dispatches"]), os.path.relpath(path, ROOT)
     return None, None
+
+
+# timed (non-counting) variants of the kernel classes, as rocprofv3 names them: the first template argument of the
+# render kernels (COUNT) and the second of trace_kernel / trace_flat_kernel is false
+PMC_NAME = {"raygen_kernel": r"^raygen_kernel", "closest_kernel": r"^closest(_flat)?_kernel<false", "shade_kernel": r"^shade_kernel",
+            "shadow_kernel": r"^shadow(_flat)?_kernel<false", "accumulate_kernel": r"^accumulate_kernel"}
 
 
 def parse():
@@ -167,8 +174,8 @@ def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, wan
                    "bvh_build": args.split, "bvh_build_seconds": float(agg.info.build_seconds),
                    "bvh_node_bytes": int(s_node), "tri_record_bytes": int(s_prim)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("trace_kernel<false, false>", "trace")[0],
-                     "traffic_source": pmc_traffic("trace_kernel<false, false>", "trace")[1],
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(r"^trace(_flat)?_kernel<false, false", "trace")[0],
+                     "traffic_source": pmc_traffic(r"^trace(_flat)?_kernel<false, false", "trace")[1],
                      "kernel": "trace_kernel<false,false>", "kernel_ms": k_ms,
                      "bytes_per_ray": bytes_per_ray, "nodes_per_ray": n_node, "prims_per_ray": n_prim},
     }
@@ -220,18 +227,29 @@ def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, wan
 
 
 def kernel_bytes(st, info, sd):
-    """Algorithmic HBM bytes of one render() per kernel class (DESIGN.md §4): structure-of-arrays path state that each
-    kernel must read/write once per item + BVH node/leaf-record bytes from the traversal counters."""
+    """Algorithmic HBM bytes of one render() per kernel class (DESIGN.md 5.2): structure-of-arrays path state that each
+    kernel must read/write once per item + the scene data its rays need.  Tree walk: BVH node / leaf-record bytes from
+    the traversal counters (demand traffic, every fetch counted).  Flat sweep (scenes of <= 64 primitives): the flat table
+    is read once per WAVE of 64 rays through scalar loads, so a ray's share is 1/64 of the entries it was offered, plus
+    the 48..80-byte record of every exact test it ran (those are per-lane loads)."""
     rec = info.prim_buffer_bytes / max(1, info.n_prims)     # mean leaf-record size of this scene
     node = info.node_bytes
     S, C, SH = st["samples"], st["closest_rays"], st["shadow_rays"]
     shaded = C                       # one shade item per closest-hit ray
+    if info.flat_prims:
+        ex_c = st["exact_tests"] * C / max(1, C + SH)       # the exact-test counter is not split by kernel class
+        ex_s = st["exact_tests"] - ex_c
+        scene_c = st["closest_prims"] * 64 / 64.0 + ex_c * rec
+        scene_s = st["shadow_prims"] * 64 / 64.0 + ex_s * rec
+    else:
+        scene_c = st["closest_nodes"] * node + st["closest_prims"] * rec
+        scene_s = st["shadow_nodes"] * node + st["shadow_prims"] * rec
     b = [0.0] * 5
     b[0] = S * (7 * 16 + 8)                                          # ray_o ray_d beta L lambda pdf rng + misc
-    b[1] = C * (4 + 8 + 32 + 16) + st["closest_nodes"] * node + st["closest_prims"] * rec
+    b[1] = C * (4 + 8 + 32 + 16) + scene_c
     b[2] = shaded * (4 + 8 + 16 + 16 + 16 + 16 + 16 + 32 + 32)       # queue misc hit beta L lambda pdf ray rng(r+w)
     b[2] += (C - S) * (32 + 16 + 8 + 4) + SH * (48 + 4) + shaded * 72   # continuation + shadow-ray writes + shading record
-    b[3] = SH * (4 + 32) + st["shadow_nodes"] * node + st["shadow_prims"] * rec + SH * 48
+    b[3] = SH * (4 + 32) + scene_s + SH * 48
     b[4] = S * (48 + 8) + (S / max(1, st["spp_rendered"])) * 64
     return b
 
@@ -310,6 +328,8 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup):
         "config": {"workload": f"{name}, SimplePathIntegrator max_depth {args.max_depth}, light + BSDF sampling, "
                                f"Gaussian filter, 4 wavelengths/sample",
                    "bvh_nodes": int(integ.aggregate.info.n_nodes), "bvh_build": args.split,
+                   "traversal": ("flat sweep of %d primitives (no tree walk)" % integ.aggregate.info.flat_prims
+                                 if integ.aggregate.info.flat_prims else "wide-BVH walk"),
                    "bvh_build_seconds": float(integ.aggregate.info.build_seconds),
                    "samples_per_gpu": samples, "closest_rays": st["closest_rays"], "shadow_rays": st["shadow_rays"],
                    "passes": st["passes"], "merge": "none" if world == 1 else "RCCL all-reduce of the f64 film per step",
@@ -325,14 +345,21 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup):
                                                           for b, m in zip(bytes_k, ms_k)]))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(KERNEL_NAMES[dom], "path")[0] if args.workload == "path" else None,
-                     "traffic_source": pmc_traffic(KERNEL_NAMES[dom], "path")[1] if args.workload == "path" else None,
+                     "traffic": pmc_traffic(PMC_NAME[KERNEL_NAMES[dom]], "path")[0] if args.workload == "path" else None,
+                     "traffic_source": pmc_traffic(PMC_NAME[KERNEL_NAMES[dom]], "path")[1] if args.workload == "path" else None,
                      "kernel": KERNEL_NAMES[dom],
                      "kernel_ms": float(ms_k[dom] / max(1.0, launches[dom])), "launches_per_step": float(launches[dom]),
                      "bytes_per_launch": bytes_k[dom] / max(1.0, launches[dom]),
                      "whole_render": {"achieved": total_bytes / (float(ms_k.sum()) * 1e-3) / 1e9,
-                                      "frac": total_bytes / (float(ms_k.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+                                      "frac": total_bytes / (float(ms_k.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                     "per_kernel_frac": {k: float(b / (m * 1e-3) / 1e9 / HBM_PEAK_GBS) if m > 0 else 0.0
+                                         for k, b, m in zip(KERNEL_NAMES, bytes_k, ms_k)}},
     }
+    if integ.aggregate.info.flat_prims and KERNEL_NAMES[dom] in ("closest_kernel", "shadow_kernel"):
+        out["roofline"]["note"] = ("the traversal kernels of this %d-primitive scene are instruction-bound by design: every wave "
+                                   "sweeps all primitives from wave-uniform (scalar-loaded) records, so their algorithmic HBM "
+                                   "bytes are a few tens of bytes per ray; the HBM-bound kernel of the frame is shade_kernel "
+                                   "(per_kernel_frac)" % integ.aggregate.info.flat_prims)
     return out, sd, integ
 
 

@@ -104,7 +104,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_fix_kernel(const uint4* __r
             *reinterpret_cast<float4*>(hits + i) = o;
         }
     };
-    pmd::sphere_fix<ANY, COUNT>(prims, defer_list, defer_count, &tc, fetch, load_t, commit);
+    __shared__ uint4 gather[128 * (TRACE_BLOCK / 64)];
+    pmd::sphere_fix<ANY, COUNT>(prims, defer_list, defer_count, gather + 128 * (threadIdx.x >> 6), &tc, fetch, load_t, commit);
     if (COUNT && tc.exact) atomicAdd(&counters[6], (unsigned long long)tc.exact);
 }
 

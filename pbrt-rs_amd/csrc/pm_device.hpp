@@ -869,14 +869,36 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
 // interval test, so the waves of this pass are dense.  Closest hit: the entry's ray already has its best non-deferred hit
 // committed; load_t(i) returns that t and commit(i, true, hit) overwrites it when a sphere is nearer.  Any hit: the ray was
 // not occluded by anything else and has not been committed; commit(i, occluded, .) finishes it.
+// The list has holes (the padding of the waves' reservations), so a wave first gathers valid entries into `buf` (LDS,
+// 128 entries per wave) and runs the tests on 64 of them at a time.
 template <bool ANY, bool COUNT, class FetchFn, class LoadTFn, class CommitFn>
 PMD void sphere_fix(const uint4* __restrict__ prims, const uint4* __restrict__ defer_list, const uint32_t* __restrict__ defer_count,
-                    TravCounters* ctr, FetchFn fetch, LoadTFn load_t, CommitFn commit) {
+                    uint4* buf, TravCounters* ctr, FetchFn fetch, LoadTFn load_t, CommitFn commit) {
     const uint32_t n = *defer_count;
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-        const uint4 ent = defer_list[e];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    uint32_t cnt = 0;                                   // wave-uniform: valid entries waiting in buf
+    for (uint32_t base = wave * 64u; base < n || cnt > 0u; base += n_waves * 64u) {
+        if (base < n) {
+            uint4 ent = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+            if (base + lane < n) ent = defer_list[base + lane];
+            const bool valid = ent.x != 0xFFFFFFFFu;
+            const unsigned long long vm = __ballot(valid);
+            if (valid) buf[cnt + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull))] = ent;
+            cnt += (uint32_t)__popcll(vm);
+            __threadfence_block();
+            if (cnt < 64u && base + n_waves * 64u < n) continue;     // gather more before running the tests
+        }
+        const uint32_t take = cnt < 64u ? cnt : 64u;
+        uint4 ent = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u), tail = ent;
+        if (lane < take) ent = buf[lane];
+        if (64u + lane < cnt) tail = buf[64u + lane];
+        __threadfence_block();
+        if (64u + lane < cnt) buf[lane] = tail;
+        cnt -= take;
+        __threadfence_block();
         Ray ray;
-        if (ent.x == 0xFFFFFFFFu || !fetch(ent.x, &ray)) continue;      // padding of a wave's reservation
+        if (ent.x == 0xFFFFFFFFu || !fetch(ent.x, &ray)) continue;
         float tmax = ANY ? ray.tmax : load_t(ent.x);
         bool found = false;
         HitRec hit; hit.prim_id = 0xFFFFFFFFu; hit.t = tmax; hit.u = 0.0f; hit.v = 0.0f;

@@ -220,7 +220,8 @@ __global__ __launch_bounds__(TB) void closest_fix_kernel(SceneArrays sc, PathArr
     auto commit = [&](uint32_t i, bool found, const HitRec& h) {
         pa.hit[queue[i]] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
     };
-    sphere_fix<false, COUNT>(sc.prims, defer_list, defer_count, &tc, fetch, load_t, commit);
+    __shared__ uint4 gather[128 * (TB / 64)];
+    sphere_fix<false, COUNT>(sc.prims, defer_list, defer_count, gather + 128 * (threadIdx.x >> 6), &tc, fetch, load_t, commit);
     if (COUNT && tc.exact) atomicAdd(&counters[6], (unsigned long long)tc.exact);
 }
 template <bool COUNT>
@@ -244,7 +245,8 @@ __global__ __launch_bounds__(TB) void shadow_fix_kernel(SceneArrays sc, PathArra
             pa.L[slot] = L;
         }
     };
-    sphere_fix<true, COUNT>(sc.prims, defer_list, defer_count, &tc, fetch, load_t, commit);
+    __shared__ uint4 gather[128 * (TB / 64)];
+    sphere_fix<true, COUNT>(sc.prims, defer_list, defer_count, gather + 128 * (threadIdx.x >> 6), &tc, fetch, load_t, commit);
     if (COUNT && tc.exact) atomicAdd(&counters[6], (unsigned long long)tc.exact);
 }
 
