@@ -247,7 +247,7 @@ def kernel_bytes(st, info, sd):
     b = [0.0] * 5
     b[0] = S * (7 * 16 + 8)                                          # ray_o ray_d beta L lambda pdf rng + misc
     b[1] = C * (4 + 8 + 32 + 16) + scene_c
-    b[2] = shaded * (4 + 8 + 16 + 16 + 16 + 16 + 16 + 32 + 32)       # queue misc hit beta L lambda pdf ray rng(r+w)
+    b[2] = shaded * (4 + 8 + 16 + 16 + 16 + 16 + 16 + 8)             # queue misc hit beta lambda ray_d rng(16 r + 8 w)
     b[2] += (C - S) * (32 + 16 + 8 + 4) + SH * (48 + 4) + shaded * 72   # continuation + shadow-ray writes + shading record
     b[3] = SH * (4 + 32) + scene_s + SH * 48
     b[4] = S * (48 + 8) + (S / max(1, st["spp_rendered"])) * 64

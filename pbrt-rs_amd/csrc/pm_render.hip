@@ -13,7 +13,9 @@
 #include "pm_ctx.h"
 #include "pm_shade.hpp"
 
+#ifndef RB
 #define RB 256          // block size of the non-traversal kernels
+#endif
 #ifndef PM_SHADE_WAVES_PER_EU
 #define PM_SHADE_WAVES_PER_EU 0
 #endif
@@ -258,6 +260,27 @@ __device__ __forceinline__ Spec4 light_L(const SceneArrays& sc, const DLight& l,
     return r;
 }
 
+// two block-wide appends behind one pair of barriers: this lane's indices in queue a / queue b (or ~0u when not wanted)
+__device__ __forceinline__ void block_append2(bool want_a, uint32_t* __restrict__ counter_a, bool want_b,
+                                              uint32_t* __restrict__ counter_b, uint32_t* lds /* [2 * (RB/64 + 1)] */,
+                                              uint32_t* idx_a, uint32_t* idx_b) {
+    const unsigned long long ma = __ballot(want_a), mb = __ballot(want_b);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t* la = lds;
+    uint32_t* lb = lds + RB / 64 + 1;
+    if (lane == 0) { la[wave] = (uint32_t)__popcll(ma); lb[wave] = (uint32_t)__popcll(mb); }
+    __syncthreads();
+    if (threadIdx.x < 2) {      // lane 0 scans queue a, lane 1 queue b
+        uint32_t* l = threadIdx.x ? lb : la;
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < RB / 64; ++w) { const uint32_t c = l[w]; l[w] = tot; tot += c; }
+        l[RB / 64] = tot ? atomicAdd(threadIdx.x ? counter_b : counter_a, tot) : 0u;
+    }
+    __syncthreads();
+    *idx_a = want_a ? la[RB / 64] + la[wave] + (uint32_t)__popcll(ma & lt) : 0xFFFFFFFFu;
+    *idx_b = want_b ? lb[RB / 64] + lb[wave] + (uint32_t)__popcll(mb & lt) : 0xFFFFFFFFu;
+}
 // block-wide append: returns this lane's index in the output queue (or ~0u when !want)
 __device__ __forceinline__ uint32_t block_append(bool want, uint32_t* __restrict__ counter, uint32_t* lds /* [RB/64 + 1] */) {
     const unsigned long long mask = __ballot(want);
@@ -279,7 +302,7 @@ __device__ __forceinline__ uint32_t block_append(bool want, uint32_t* __restrict
 // SurfaceInteraction::get_bsdf (core/interaction.rs:186-215, materials/material.rs:122-195) at the sampled wavelengths;
 // may terminate the secondary wavelengths (pdfw is updated in registers and in the path state)
 __device__ __forceinline__ Bsdf make_bsdf(const SceneArrays& sc, const PathArrays& pa, const SurfInt& si, uint32_t prim_id,
-                                          const float* lam, float* pdfw, uint32_t slot) {
+                                          const float* lam, uint32_t slot) {
     const DMaterial mat = sc.materials[sc.prim_material[prim_id]];
     Bsdf bsdf;
     bsdf.type = mat.type;
@@ -290,7 +313,9 @@ __device__ __forceinline__ Bsdf make_bsdf(const SceneArrays& sc, const PathArray
     } else {
         bsdf.refl = spec_c(0.0f);
         bsdf.eta = spectrum_at(sc.pool, mat.spec, lam[0]);
-        if (mat.spec.kind != PM_SPEC_CONSTANT) {   // SampledWavelengths::terminate_secondary
+        if (mat.spec.kind != PM_SPEC_CONSTANT) {   // SampledWavelengths::terminate_secondary (the only reader of pdf here)
+            const float4 p4 = pa.pdf[slot];
+            float pdfw[4] = {p4.x, p4.y, p4.z, p4.w};
             if (!(pdfw[1] == 0.0f && pdfw[2] == 0.0f && pdfw[3] == 0.0f)) { pdfw[0] /= 4.0f; pdfw[1] = 0.0f; pdfw[2] = 0.0f; pdfw[3] = 0.0f; }
             pa.pdf[slot] = make_float4(pdfw[0], pdfw[1], pdfw[2], pdfw[3]);
         }
@@ -305,7 +330,7 @@ __device__ __forceinline__ Bsdf make_bsdf(const SceneArrays& sc, const PathArray
 __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ qin,
                                                    const uint32_t* __restrict__ count_in, uint32_t* __restrict__ qout,
                                                    uint32_t* __restrict__ count_out, uint32_t* __restrict__ shadow_count) {
-    __shared__ uint32_t lds_a[RB / 64 + 1], lds_b[RB / 64 + 1];
+    __shared__ uint32_t lds_ab[2 * (RB / 64 + 1)];
     const uint32_t i = blockIdx.x * RB + threadIdx.x;
     const uint32_t n_in = *count_in;
     if (blockIdx.x * RB >= n_in) return;             // whole block idle (uniform exit, before any barrier)
@@ -317,18 +342,18 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
     if (live && misc.x != 0xFFFFFFFFu) {
         const float4 hv = pa.hit[slot];
         const uint32_t prim_id = __float_as_uint(hv.x);
-        float4 b4 = pa.beta[slot], L4 = pa.L[slot];
+        float4 b4 = pa.beta[slot];
         const float4 l4 = pa.lambda[slot];
-        float4 p4 = pa.pdf[slot];
-        float beta[4] = {b4.x, b4.y, b4.z, b4.w}, L[4] = {L4.x, L4.y, L4.z, L4.w};
+        float beta[4] = {b4.x, b4.y, b4.z, b4.w};
         const float lam[4] = {l4.x, l4.y, l4.z, l4.w};
-        float pdfw[4] = {p4.x, p4.y, p4.z, p4.w};
         int depth = (int)(misc.x & 0xFFu);
         bool specular = ((misc.x >> 8) & 1u) != 0u;
-        const float4 ro4 = pa.ray_o[slot], rd4 = pa.ray_d[slot];
-        const f3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
+        const float4 rd4 = pa.ray_d[slot];
+        const f3 rd = mk3(rd4.x, rd4.y, rd4.z);
         if (prim_id == 0xFFFFFFFFu) {
             if (!rc.sample_lights || specular) {
+                const float4 L4 = pa.L[slot];           // only escaped rays touch L here (hits: the shadow kernel adds NEE)
+                float L[4] = {L4.x, L4.y, L4.z, L4.w};
                 for (int k = 0; k < rc.n_infinite; ++k) {
                     const Spec4 le = light_L(sc, sc.lights[sc.infinite[k]], lam);
 #pragma unroll
@@ -341,9 +366,11 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
             // ---- interaction
             const uint32_t ref = sc.prim_ref[prim_id];
             SurfInt si;
-            if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], ro, rd, hv.y);
-            else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
-            Bsdf bsdf = make_bsdf(sc, pa, si, prim_id, lam, pdfw, slot);
+            if ((ref >> 30) == PM_PRIM_SPHERE) {
+                const float4 ro4 = pa.ray_o[slot];      // only the sphere's interaction needs the ray origin
+                si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], mk3(ro4.x, ro4.y, ro4.z), rd, hv.y);
+            } else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
+            Bsdf bsdf = make_bsdf(sc, pa, si, prim_id, lam, slot);
             const f3 wo = -rd;
             const uint4 r4 = pa.rng[slot];
             Rng rng; rng.state = ((unsigned long long)r4.y << 32) | r4.x; rng.inc = ((unsigned long long)r4.w << 32) | r4.z;
@@ -427,7 +454,7 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                 specular = false;
                 wi_next = wi; ok = true;
             }
-            pa.rng[slot] = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), (uint32_t)rng.inc, (uint32_t)(rng.inc >> 32));
+            reinterpret_cast<uint2*>(pa.rng + slot)[0] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));   // inc never changes
             if (ok && !(beta[0] == 0.0f && beta[1] == 0.0f && beta[2] == 0.0f && beta[3] == 0.0f)) {
                 const f3 no = offset_ray_origin(si, wi_next);
                 pa.ray_o[slot] = make_float4(no.x, no.y, no.z, 0.f);
@@ -438,9 +465,9 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
             }
         }
     }
-    const uint32_t oi = block_append(cont, count_out, lds_a);
+    uint32_t oi, si_;
+    block_append2(cont, count_out, want_shadow, shadow_count, lds_ab, &oi, &si_);
     if (cont) qout[oi] = slot;
-    const uint32_t si_ = block_append(want_shadow, shadow_count, lds_b);
     if (want_shadow) pa.shq[si_] = slot;
 }
 
@@ -464,9 +491,7 @@ __global__ __launch_bounds__(RB) void shade_rw_kernel(RenderConst rc, SceneArray
         const float4 hv = pa.hit[slot];
         const uint32_t prim_id = __float_as_uint(hv.x);
         const float4 l4 = pa.lambda[slot];
-        const float4 p4 = pa.pdf[slot];
         const float lam[4] = {l4.x, l4.y, l4.z, l4.w};
-        float pdfw[4] = {p4.x, p4.y, p4.z, p4.w};
         const int depth = (int)(misc.x & 0xFFu);
         float Lr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         bool done = true;
@@ -483,12 +508,12 @@ __global__ __launch_bounds__(RB) void shade_rw_kernel(RenderConst rc, SceneArray
             SurfInt si;
             if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], ro, rd, hv.y);
             else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
-            const Bsdf bsdf = make_bsdf(sc, pa, si, prim_id, lam, pdfw, slot);
+            const Bsdf bsdf = make_bsdf(sc, pa, si, prim_id, lam, slot);
             const f3 wo = -rd;
             const uint4 r4 = pa.rng[slot];
             Rng rng; rng.state = ((unsigned long long)r4.y << 32) | r4.x; rng.inc = ((unsigned long long)r4.w << 32) | r4.z;
             f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
-            pa.rng[slot] = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), (uint32_t)rng.inc, (uint32_t)(rng.inc >> 32));
+            reinterpret_cast<uint2*>(pa.rng + slot)[0] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));   // inc never changes
             const f3 wp = sample_uniform_sphere(u2);
             Spec4 f = bsdf_eval(bsdf, wo, wp);
             if (!spec_zero(f)) {
