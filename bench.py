@@ -332,7 +332,7 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup):
                                  if integ.aggregate.info.flat_prims else "wide-BVH walk"),
                    "bvh_build_seconds": float(integ.aggregate.info.build_seconds),
                    "samples_per_gpu": samples, "closest_rays": st["closest_rays"], "shadow_rays": st["shadow_rays"],
-                   "passes": st["passes"], "merge": "none" if world == 1 else "RCCL all-reduce of the f64 film per step",
+                   "passes": st["passes"], "merge": "none" if world == 1 else ("RCCL" if args.backend == "nccl" else args.backend) + " all-reduce of the f64 film per step",
                    "bytes_per_sample": total_bytes / samples,
                    "closest_nodes_per_ray": st_c["closest_nodes"] / max(1, st_c["closest_rays"]),
                    "closest_prims_per_ray": st_c["closest_prims"] / max(1, st_c["closest_rays"]),
