@@ -520,11 +520,6 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
         if (active) {
             // ---- one node step (the pop of an exhausted group is merged into it)
             bool ended = (ANY && (found || sure)) || ++steps > PM_WALK_GUARD;
-#ifdef PM_DEBUG_LONGWALK
-            if (steps == 20000u)
-                printf("LONGWALK any=%d o=%a %a %a d=%a %a %a tmax=%a tcull=%a sp=%d qn=%u\n", (int)ANY, ray.o.x, ray.o.y, ray.o.z,
-                       ray.d.x, ray.d.y, ray.d.z, ray.tmax, tcull, sp, qn);
-#endif
             uint32_t pm = cur.y & 0xFFu;
             if (!ended && pm == 0u) {
                 if (sp == 0) ended = true;
