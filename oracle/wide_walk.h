@@ -195,6 +195,8 @@ struct WideWalker {
         }
         return ft;
     }
+    // pm_device.hpp trace_flat + deferred_fix: the lean sweep (pre-filters + exact triangle round), then the second pass
+    // (deferred spheres / patches, or - for a slow ray - everything again through the exact tests)
     bool walk_flat(const FlatTable& ft, V3 ro, V3 rd, float ray_tmax, bool any_hit, uint32_t* hid, float* ht, float* hu, float* hv,
                    Counters* ctr) const {
         *hid = 0xFFFFFFFFu; *ht = ray_tmax; *hu = 0; *hv = 0;
@@ -202,11 +204,13 @@ struct WideWalker {
             const float dsum = std::fabs(rd.x) + std::fabs(rd.y) + std::fabs(rd.z), osum = std::fabs(ro.x) + std::fabs(ro.y) + std::fabs(ro.z);
             if (!(dsum > 0.0f && dsum < std::numeric_limits<float>::infinity() && osum < std::numeric_limits<float>::infinity())) return false;
         }
-        const uint32_t CAND_MAX = 4;
+        const uint32_t CAND_MAX = 4, PATCH_TAG = 0x40000000u;       // PM_FLAT_CAND_MAX
         const float R = maxabs(ro), D = maxabs(rd);
-        float t_max = ray_tmax, tcull = ray_tmax;
-        bool sure = false, found = false;
+        float tcull = ray_tmax;
+        float t_max = ray_tmax;
+        bool sure = false, found = false, slow = false;
         std::vector<uint32_t> deferred;
+        auto defer_prim = [&](uint32_t tagged) { if (deferred.size() < 3) deferred.push_back(tagged); else slow = true; };
         auto test_now = [&](uint32_t type, uint32_t unit) {
             if (ctr) ctr->exact_tests++;
             uint32_t id; float t, u, v;
@@ -214,19 +218,13 @@ struct WideWalker {
             return false;
         };
         for (uint32_t unit : ft.spheres) {
-            if (any_hit && (found || sure)) break;
+            if (slow) break;
             if (ctr) ctr->prims_tested++;
-            bool now = !defer_spheres;
-            if (!now) {
-                const float* f = reinterpret_cast<const float*>(prims + (size_t)unit * 16);
-                if (sphere_prefilter(ro, rd, R, D, f, f[12], f[18], f[19], tcull)) {
-                    if (deferred.size() < 2) deferred.push_back(unit); else now = true;
-                }
-            }
-            if (now && test_now(0, unit)) tcull = rmin(tcull, *ht);
+            const float* f = reinterpret_cast<const float*>(prims + (size_t)unit * 16);
+            if (sphere_prefilter(ro, rd, R, D, f, f[12], f[18], f[19], tcull)) defer_prim(unit);
         }
-        for (uint32_t unit : ft.patches) {
-            if (any_hit && (found || sure)) break;
+        for (uint32_t unit : ft.patches) {                  // reference arithmetic at once
+            if (slow || (any_hit && found)) break;
             if (ctr) ctr->prims_tested++;
             if (test_now(1, unit)) tcull = rmin(tcull, *ht);
         }
@@ -235,32 +233,36 @@ struct WideWalker {
         FlatCull cull{tcull, 1.0f};
         const float KD = 7.62939453125e-06f * D, R2 = 2.0f * R, epsb_ray = 8e-7f * std::fmaf(9.0f, R, D);
         for (const FlatTri& t : ft.tris) {
-            if (any_hit && (found || sure)) break;
+            if (slow || (any_hit && (found || sure))) break;
             if (ctr) ctr->prims_tested++;
             float ln, ld;
             int cls = tri_prefilter_flat(ro, rd, KD, R2, t.v0, t.e1, t.e2, t.n, t.L, t.c1, t.kll, epsb_ray, &cull, !any_hit, &ln, &ld);
             if (cls != 0) {
                 if (cls == 2) sure = true;
                 if (cand.size() < CAND_MAX) cand.push_back(Cand{t.unit, ln, ld});
-                else (void)test_now(2, t.unit);
+                else slow = true;
             }
         }
-        for (const Cand& cu : cand) {
-            if (cu.ln * cull.cd > cull.cn * cu.ld) continue;        // behind another certain hit (filtered before the round)
-            if (any_hit && found) break;
-            (void)test_now(2, cu.unit);
+        if (!slow) {
+            const float tconf = next_float_down(cull.cn / cull.cd);
+            for (const Cand& cu : cand) {
+                if (cu.ln * cull.cd > cull.cn * cu.ld) continue;        // behind another certain hit (filtered before the round)
+                if (any_hit && found) break;
+                (void)test_now(2, cu.unit);
+            }
+            if (sure && !(found && (any_hit || *ht <= tconf))) { slow = true; if (ctr) ctr->fallback_walks++; }
         }
-        if (sure && !(found && (any_hit || !(*ht * cull.cd > cull.cn)))) {        // exact re-sweep (never seen)
-            if (ctr) ctr->fallback_walks++;
-            t_max = ray_tmax; found = false; deferred.clear();
+        if (slow) {             // second pass, slow entry: everything again, exactly
+            t_max = ray_tmax; found = false;
             *hid = 0xFFFFFFFFu; *ht = ray_tmax; *hu = 0; *hv = 0;
             for (uint32_t unit : ft.spheres) { if (any_hit && found) break; if (ctr) ctr->prims_tested++; (void)test_now(0, unit); }
             for (uint32_t unit : ft.patches) { if (any_hit && found) break; if (ctr) ctr->prims_tested++; (void)test_now(1, unit); }
             for (const FlatTri& t : ft.tris) { if (any_hit && found) break; if (ctr) ctr->prims_tested++; (void)test_now(2, t.unit); }
+            return found;
         }
-        for (uint32_t unit : deferred) {                            // the kernel's second pass (sphere_fix)
+        for (uint32_t tagged : deferred) {                          // second pass, ordinary entry
             if (any_hit && found) break;
-            (void)test_now(0, unit);
+            if (tagged & PATCH_TAG) (void)test_now(1, tagged & ~PATCH_TAG); else (void)test_now(0, tagged);
         }
         return found;
     }

@@ -48,13 +48,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR void trace_kernel(const P
 }
 
 // the same entry points for scenes small enough to be swept without a tree (pm_device.hpp trace_flat)
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool PATCH>
 __global__ __launch_bounds__(TRACE_BLOCK) PM_FLAT_ATTR void trace_flat_kernel(PmFlatScene fs, const uint4* __restrict__ prims,
                                                                  const PmRay* __restrict__ rays, uint32_t n,
                                                                  PmHit* __restrict__ hits, uint8_t* __restrict__ occ,
                                                                  uint4* __restrict__ defer_list, uint32_t* __restrict__ defer_count,
+                                                                 uint32_t* __restrict__ slow_list,
                                                                  unsigned long long* __restrict__ counters) {
-    __shared__ uint32_t cand[3 * PM_CAND_MAX * TRACE_BLOCK];     // units, then the lower bounds of t as fractions (numerators, denominators)
+    __shared__ uint32_t cand[3 * PM_FLAT_CAND_MAX * TRACE_BLOCK];     // units, then the lower bounds of t as fractions (numerators, denominators)
     pmd::TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, pmd::Ray* ray) -> bool {
         const float4* rp = reinterpret_cast<const float4*>(rays + i);
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) PM_FLAT_ATTR void trace_flat_kernel(Pm
             *reinterpret_cast<float4*>(hits + i) = o;
         }
     };
-    pmd::trace_flat<ANY, COUNT>(fs, prims, n, cand + threadIdx.x, TRACE_BLOCK, defer_list, defer_count, &tc, fetch, commit);
+    pmd::trace_flat<ANY, COUNT, PATCH>(fs, prims, n, cand + threadIdx.x, TRACE_BLOCK, defer_list, defer_count, slow_list,
+                                defer_count + PM_WORK_SLOTS, &tc, fetch, commit);
     if (COUNT) {
         unsigned long long pp = tc.prims, ee = tc.exact, ff = tc.fallback;
         for (int off = 32; off > 0; off >>= 1) { pp += __shfl_down(pp, off); ee += __shfl_down(ee, off); ff += __shfl_down(ff, off); }
@@ -81,12 +83,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) PM_FLAT_ATTR void trace_flat_kernel(Pm
     }
 }
 
-// exact tests of the spheres that trace_kernel deferred (pm_device.hpp sphere_fix): dense waves
+// second pass (pm_device.hpp deferred_fix): exact tests of what trace_kernel / trace_flat_kernel deferred, dense waves
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(TRACE_BLOCK) void trace_fix_kernel(const uint4* __restrict__ prims, const PmRay* __restrict__ rays,
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_fix_kernel(PmFlatScene fs, const uint4* __restrict__ prims, const PmRay* __restrict__ rays,
                                                                 PmHit* __restrict__ hits, uint8_t* __restrict__ occ,
                                                                 const uint4* __restrict__ defer_list,
                                                                 const uint32_t* __restrict__ defer_count,
+                                                                const uint32_t* __restrict__ slow_list,
                                                                 unsigned long long* __restrict__ counters) {
     pmd::TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, pmd::Ray* ray) -> bool {
@@ -105,8 +108,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_fix_kernel(const uint4* __r
         }
     };
     __shared__ uint4 gather[128 * (TRACE_BLOCK / 64)];
-    pmd::sphere_fix<ANY, COUNT>(prims, defer_list, defer_count, gather + 128 * (threadIdx.x >> 6), &tc, fetch, load_t, commit);
+    pmd::deferred_fix<ANY, COUNT>(fs, prims, defer_list, defer_count, slow_list, defer_count + PM_WORK_SLOTS,
+                                  gather + 128 * (threadIdx.x >> 6), &tc, fetch, load_t, commit);
     if (COUNT && tc.exact) atomicAdd(&counters[6], (unsigned long long)tc.exact);
+    if (COUNT && tc.prims) atomicAdd(&counters[2], (unsigned long long)tc.prims);
 }
 
 int pm_gpu_build_tris(pm_ctx* c, int max_leaf, std::string& err);   // pm_gpu_build.hip
@@ -129,7 +134,7 @@ extern "C" int pm_create(int device_id, pm_ctx** out) {
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc(&c->d_work, 2 * PM_WORK_SLOTS * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&c->d_work, 3 * PM_WORK_SLOTS * sizeof(uint32_t)) != hipSuccess ||
         hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) {
         delete c;
         return PM_ERR_HIP;
@@ -148,6 +153,7 @@ extern "C" void pm_destroy(pm_ctx* c) {
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_work) (void)hipFree(c->d_work);
     if (c->d_defer) (void)hipFree(c->d_defer);
+    if (c->d_slow) (void)hipFree(c->d_slow);
     if (c->flat.tris) (void)hipFree((void*)c->flat.tris);
     if (c->flat.units) (void)hipFree((void*)c->flat.units);
     if (c->d_stage_in) (void)hipFree(c->d_stage_in);
@@ -349,13 +355,13 @@ static int trace_impl(pm_ctx* c, const PmRay* rays, uint64_t n, void* out, size_
     // persistent waves pull ray indices from a work counter; one launch covers at most 2^30 rays (2^24 when the scene
     // holds spheres: the deferred-sphere list has one 16-byte entry per ray of the launch)
     const bool has_spheres = !c->scene.spheres.empty();
-    const uint64_t chunk = has_spheres ? (1ull << 24) : (1ull << 30);
+    const uint64_t chunk = (has_spheres || c->flat.tris) ? (1ull << 24) : (1ull << 30);
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
     { int r = ensure_defer(c, (size_t)std::min<uint64_t>(chunk, n)); if (r) return r; }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     for (uint64_t k = 0; k < n_chunks; ++k) {
         const uint32_t slot = (uint32_t)(k % PM_WORK_SLOTS);     // stream-ordered: a slot is free again when it comes round
-        if (slot == 0) HIPCHK(c, hipMemsetAsync(c->d_work, 0, 2 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
+        if (slot == 0) HIPCHK(c, hipMemsetAsync(c->d_work, 0, 3 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
         const uint64_t b = k * chunk;
         const uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - b);
         const uint32_t grid = std::min<uint32_t>((m + TRACE_BLOCK - 1) / TRACE_BLOCK, (uint32_t)c->n_cu * PM_BLOCKS_PER_CU);
@@ -363,25 +369,26 @@ static int trace_impl(pm_ctx* c, const PmRay* rays, uint64_t n, void* out, size_
         uint8_t* oo = ANY ? (uint8_t*)d_out + b : nullptr;
         if (c->flat.tris) {
             const uint32_t fgrid = std::min<uint32_t>((m + TRACE_BLOCK - 1) / TRACE_BLOCK, (uint32_t)c->n_cu * PM_FLAT_BLOCKS_PER_CU);
-            if (c->counting)
-                hipLaunchKernelGGL((trace_flat_kernel<ANY, true>), dim3(fgrid), dim3(TRACE_BLOCK), 0, c->stream, c->flat, c->d_prims,
-                                   d_rays + b, m, oh, oo, c->d_defer, c->d_work + PM_WORK_SLOTS + slot, c->d_counters);
-            else
-                hipLaunchKernelGGL((trace_flat_kernel<ANY, false>), dim3(fgrid), dim3(TRACE_BLOCK), 0, c->stream, c->flat, c->d_prims,
-                                   d_rays + b, m, oh, oo, c->d_defer, c->d_work + PM_WORK_SLOTS + slot, c->d_counters);
+            const bool patch = c->flat.n_patch > 0;
+            auto kernel = c->counting ? (patch ? trace_flat_kernel<ANY, true, true> : trace_flat_kernel<ANY, true, false>)
+                                      : (patch ? trace_flat_kernel<ANY, false, true> : trace_flat_kernel<ANY, false, false>);
+            hipLaunchKernelGGL(kernel, dim3(fgrid), dim3(TRACE_BLOCK), 0, c->stream, c->flat, c->d_prims, d_rays + b, m, oh, oo,
+                               c->d_defer, c->d_work + PM_WORK_SLOTS + slot, c->d_slow, c->d_counters);
         } else {
             auto kernel = c->counting ? (has_spheres ? trace_kernel<ANY, true, true> : trace_kernel<ANY, true, false>)
                                       : (has_spheres ? trace_kernel<ANY, false, true> : trace_kernel<ANY, false, false>);
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_nodes, c->d_prims, d_rays + b, m, oh, oo,
                                c->d_work + slot, c->refill, c->d_defer, c->d_counters);
         }
-        if (has_spheres) {
+        if (has_spheres || c->flat.tris) {      // the flat sweep defers patches and rare cases too
             if (c->counting)
-                hipLaunchKernelGGL((trace_fix_kernel<ANY, true>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_prims, d_rays + b,
-                                   oh, oo, c->d_defer, c->d_work + PM_WORK_SLOTS + slot, c->d_counters);
+                hipLaunchKernelGGL((trace_fix_kernel<ANY, true>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->flat, c->d_prims,
+                                   d_rays + b, oh, oo, c->d_defer, c->d_work + PM_WORK_SLOTS + slot, c->flat.tris ? c->d_slow : nullptr,
+                                   c->d_counters);
             else
-                hipLaunchKernelGGL((trace_fix_kernel<ANY, false>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_prims, d_rays + b,
-                                   oh, oo, c->d_defer, c->d_work + PM_WORK_SLOTS + slot, c->d_counters);
+                hipLaunchKernelGGL((trace_fix_kernel<ANY, false>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->flat, c->d_prims,
+                                   d_rays + b, oh, oo, c->d_defer, c->d_work + PM_WORK_SLOTS + slot, c->flat.tris ? c->d_slow : nullptr,
+                                   c->d_counters);
         }
     }
     HIPCHK(c, hipGetLastError());

@@ -50,10 +50,11 @@ struct pm_ctx {
     PmWideNode* d_nodes = nullptr;
     uint4* d_prims = nullptr;
     unsigned long long* d_counters = nullptr;   // [1] nodes [2] prims [3] overflow [4] shadow nodes [5] shadow prims [6] exact [7] fallback
-    uint32_t* d_work = nullptr;                 // PM_WORK_SLOTS work-item counters of the persistent traversal kernels,
-                                                // then PM_WORK_SLOTS entry counts of the deferred-sphere list (same slot index)
+    uint32_t* d_work = nullptr;                 // PM_WORK_SLOTS work-item counters of the persistent traversal kernels, then
+                                                // PM_WORK_SLOTS entry counts of the deferred list, then of the slow list
     PmFlatScene flat = {nullptr, nullptr, 0, 0, 0};   // device flat table; n_* all zero = walk the tree
     uint32_t flat_max = PM_FLAT_MAX_PRIMS;      // scenes of at most this many primitives are swept flat (0: never)
+    uint32_t* d_slow = nullptr;                 // slow rays of ONE flat-sweep launch (work items; same capacity as d_defer)
     uint4* d_defer = nullptr;                   // deferred (work item, sphere, sphere) entries of ONE traversal launch
     size_t defer_cap = 0;                       // ... in entries; stays null for scenes without spheres
     int n_cu = 256;
@@ -82,13 +83,15 @@ static inline bool is_device_ptr(const void* p) {
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 static inline int ensure(pm_ctx* c, void** buf, size_t* cap, size_t need);
-// room for one deferred-sphere entry per work item of a traversal launch (only scenes that hold spheres defer)
+// room for one second-pass entry per work item of a traversal launch (scenes with spheres, and every flat-swept scene)
 static inline int ensure_defer(pm_ctx* c, size_t items) {
     // + what the waves of the largest traversal grid can leave unused of their reservations (pm_device.hpp DeferWriter)
     items += (size_t)c->n_cu * PM_FLAT_BLOCKS_PER_CU * (TRACE_BLOCK / 64) * 256;
-    if (c->scene.spheres.empty() || c->defer_cap >= items) return PM_OK;
+    if ((c->scene.spheres.empty() && !c->flat.tris) || c->defer_cap >= items) return PM_OK;
     if (c->d_defer) { HIPCHK(c, hipFree(c->d_defer)); c->d_defer = nullptr; c->defer_cap = 0; }
+    if (c->d_slow) { HIPCHK(c, hipFree(c->d_slow)); c->d_slow = nullptr; }
     HIPCHK(c, hipMalloc((void**)&c->d_defer, items * sizeof(uint4)));
+    HIPCHK(c, hipMalloc((void**)&c->d_slow, items * sizeof(uint32_t)));
     c->defer_cap = items;
     return PM_OK;
 }

@@ -322,7 +322,7 @@ PMD int tri_classify(float det, float uu, float vv, float tt, float L, float S, 
 // ---- float pre-filter for spheres: false = the exact (interval) test cannot accept this sphere with t <= tcull.
 // The interval test costs ~1500 instructions and a wave pays for it as soon as ONE lane runs it, so spheres that pass are
 // not tested inside the walk: the (ray, sphere) pair goes to a global list and a second, dense kernel runs the exact
-// tests (sphere_fix below).  Plain f32 in object space with forward error bounds; m_norm / t_norm (from the record) bound
+// tests (deferred_fix below).  Plain f32 in object space with forward error bounds; m_norm / t_norm (from the record) bound
 // the rounding of the transform exactly as Transform * Point3fi does (gamma(3) * sum of |terms|, core/transform.rs).  The
 // interval test itself rejects whenever its discriminant interval reaches below zero, so rejecting where the real
 // discriminant is negative by more than the bound can never remove a hit.  The CPU walker repeats these operations.
@@ -366,7 +366,7 @@ struct DeferWriter {
         for (uint32_t i = next + lane; i < end; i += 64u) list[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u);
         next = end;
     }
-    PMD void push(bool defer, uint32_t lane, uint32_t item, uint32_t s0, uint32_t s1) {
+    PMD void push(bool defer, uint32_t lane, uint32_t item, uint32_t s0, uint32_t s1, uint32_t s2) {
         const unsigned long long dm = __ballot(defer);
         const uint32_t n = (uint32_t)__popcll(dm);
         if (n == 0u) return;
@@ -374,15 +374,45 @@ struct DeferWriter {
             pad(lane);
             uint32_t base = 0;
             if (lane == 0u) base = atomicAdd(count, PM_DEFER_CHUNK);
-            next = __shfl(base, 0);
+            next = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);       // a scalar register, not 64 copies
             end = next + PM_DEFER_CHUNK;
         }
-        if (defer) list[next + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = make_uint4(item, s0, s1, 0u);
+        if (defer) list[next + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = make_uint4(item, s0, s1, s2);
+        next += n;
+    }
+};
+
+// the same for the (rare) slow rays of the flat sweep: a list of work items, 8 reserved at a time (little padding: the
+// second pass sweeps the whole table for them, so its waves must be full), padding = ~0
+#define PM_SLOW_CHUNK 8u
+struct SlowWriter {
+    uint32_t* list; uint32_t* count; uint32_t next, end;
+    PMD void pad(uint32_t lane) {
+        for (uint32_t i = next + lane; i < end; i += 64u) list[i] = 0xFFFFFFFFu;
+        next = end;
+    }
+    PMD void push(bool slow, uint32_t lane, uint32_t item) {
+        const unsigned long long dm = __ballot(slow);
+        const uint32_t n = (uint32_t)__popcll(dm);
+        if (n == 0u) return;
+        if (next + n > end) {
+            pad(lane);
+            uint32_t base = 0;
+            const uint32_t reserve = ((n + PM_SLOW_CHUNK - 1u) / PM_SLOW_CHUNK) * PM_SLOW_CHUNK;      // n may exceed a chunk
+            if (lane == 0u) base = atomicAdd(count, reserve);
+            next = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);       // a scalar register, not 64 copies
+            end = next + reserve;
+        }
+        if (slow) list[next + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = item;
         next += n;
     }
 };
 
 #define PM_CAND_MAX 4
+// The flat sweep meets candidates in table order, not front to back, so now and then a ray collects more than 4; a wave
+// makes as many exact-test trips as its busiest lane has candidates, so those rays are NOT given a deeper queue (measured:
+// depth 6 costs 14 %) but handed to the slow list.
+#define PM_FLAT_CAND_MAX 4
 PMD float safe_rcp_dir(float d) { return fabsf(d) < 1e-18f ? copysignf(1e18f, d) : 1.0f / d; }
 #define PM_NODE_MARGIN 2.384185791015625e-07f   /* 4 * 2^-24: rounding of the pre-scaled slab evaluation */
 #define PM_WALK_GUARD (1u << 22)                /* per-ray bound on node steps (a corrupt buffer cannot hang a wave) */
@@ -476,7 +506,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                     if (!ANY || !defer) commit(item, found, hit);
                 } else { exact_mode = true; if (COUNT) ctr->fallback++; start_walk(); }
             }
-            if (SPH) dw.push(defer, lane, item, sph0, sph1);      // wave-uniform control flow here
+            if (SPH) dw.push(defer, lane, item, sph0, sph1, 0xFFFFFFFFu);      // wave-uniform control flow here
             // ---- idle lanes fetch the next items
             if (wnext >= wend && more) {
                 uint32_t base = 0;
@@ -664,9 +694,14 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
 
 // ---- scenes of at most PM_FLAT_MAX_PRIMS primitives: no tree.  Every wave takes 64 consecutive work items and sweeps the
 // whole flat table (pm_layout.h) in lock step: the records are wave-uniform (scalar loads), nothing diverges but the
-// bookkeeping, and there are no node steps.  Spheres go through sphere_prefilter and are deferred, patches are tested at
-// once (reference arithmetic), triangles go through tri_prefilter_flat into the candidate queue exactly as in
-// trace_persistent; then the exact round, the confirmation and (never seen) the exact re-sweep.
+// bookkeeping, and there are no node steps.  The sweep kernel is kept LEAN - pre-filters, the exact triangle test and (only
+// in the variant for scenes that hold patches) the bilinear patch test - because its speed hangs on registers
+// (occupancy): every interval-arithmetic sphere test and every rare case goes to the second pass (deferred_fix), which
+// runs them with all lanes busy:
+//   * spheres that pass sphere_prefilter are DEFERRED: up to three per ray travel in the ray's list entry;
+//   * a fourth deferred sphere, a fifth triangle candidate, or exact tests that do not confirm what culling assumed make
+//     the ray SLOW: the second pass redoes it from scratch with exact tests only (counted in fallback).
+// Triangles go through tri_prefilter_flat into the candidate queue as in trace_persistent, then the exact round.
 using FlatScene = PmFlatScene;
 // Read-only scene data addressed wave-uniformly: loads through the constant address space become scalar loads (one per
 // wave, into SGPRs) instead of 64 identical vector loads.
@@ -679,13 +714,17 @@ struct cuint4_p {
 PMD cuint4_p as_uniform(const uint4* p) { cuint4_p r; r.p = (const u32x4_t __attribute__((address_space(4))) *)p; return r; }
 PMD cuint_p as_uniform(const uint32_t* p) { return (cuint_p)p; }
 
-template <bool ANY, bool COUNT, class FetchFn, class CommitFn>
+#define PM_DEFER_PATCH 0x40000000u      /* deferred unit is a patch record (otherwise a sphere record) */
+#define PM_DEFER_NONE 0xFFFFFFFFu
+
+template <bool ANY, bool COUNT, bool PATCH, class FetchFn, class CommitFn>
 PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_items, uint32_t* cand, int stride,
-                    uint4* __restrict__ defer_list, uint32_t* __restrict__ defer_count, TravCounters* ctr, FetchFn fetch,
-                    CommitFn commit) {
+                    uint4* __restrict__ defer_list, uint32_t* __restrict__ defer_count, uint32_t* __restrict__ slow_list,
+                    uint32_t* __restrict__ slow_count, TravCounters* ctr, FetchFn fetch, CommitFn commit) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     DeferWriter dw; dw.list = defer_list; dw.count = defer_count; dw.next = 0u; dw.end = 0u;
+    SlowWriter sw; sw.list = slow_list; sw.count = slow_count; sw.next = 0u; sw.end = 0u;
     for (uint32_t base = wave * 64u; base < n_items; base += n_waves * 64u) {
         const uint32_t item = base + lane;
         Ray ray; ray.o = mk3(0.f, 0.f, 0.f); ray.d = mk3(0.f, 0.f, 1.f); ray.tmax = 0.f;
@@ -700,90 +739,60 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
             }
         }
         const float R = maxc3(abs3(ray.o)), D = maxc3(abs3(ray.d));
-        float tmax = ray.tmax, tcull = ray.tmax;
-        bool sure = false, found = false;
-        uint32_t qn = 0, sph0 = 0xFFFFFFFFu, sph1 = 0xFFFFFFFFu;
+        float tmax = ray.tmax;
+        float tcull = ray.tmax;                     // spheres never lower it, patches do; triangles cull by the fraction below
+        bool sure = false, found = false, slow = false;
+        uint32_t qn = 0, d0 = PM_DEFER_NONE, d1 = PM_DEFER_NONE, d2 = PM_DEFER_NONE;
         HitRec hit; hit.prim_id = 0xFFFFFFFFu; hit.t = ray.tmax; hit.u = 0.0f; hit.v = 0.0f;
-
-        auto test_sphere_now = [&](uint32_t unit) {
-            const uint4* r = prims + unit;
-            float m[12];
-            const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
-            m[0] = __uint_as_float(r0.x); m[1] = __uint_as_float(r0.y); m[2] = __uint_as_float(r0.z); m[3] = __uint_as_float(r0.w);
-            m[4] = __uint_as_float(r1.x); m[5] = __uint_as_float(r1.y); m[6] = __uint_as_float(r1.z); m[7] = __uint_as_float(r1.w);
-            m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
-            const float radius = __uint_as_float(r3.x), zmin = __uint_as_float(r3.y), zmax = __uint_as_float(r3.z),
-                        phimax = __uint_as_float(r3.w);
-            if (COUNT) ctr->exact++;
-            SphereHit sh;
-            if (intersect_sphere(ray.o, ray.d, tmax, m, radius, zmin, zmax, phimax, &sh)) {
-                tmax = sh.t; tcull = fminf(tcull, sh.t); found = true; hit.prim_id = r4.x; hit.t = sh.t;
-                const float th0 = acosf(fminf(fmaxf(zmin / radius, -1.0f), 1.0f));
-                const float th1 = acosf(fminf(fmaxf(zmax / radius, -1.0f), 1.0f));
-                const float th = acosf(fminf(fmaxf(sh.p_obj.z / radius, -1.0f), 1.0f));
-                hit.u = sh.phi / phimax; hit.v = (th - th0) / (th1 - th0);
-            }
-        };
-        auto test_patch_now = [&](uint32_t unit, bool is_tri) {
-            const uint4* r = prims + unit;
-            const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
-            const f3 p00 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
-            const f3 p10 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
-            const f3 p01 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
-            f3 p11 = p01;
-            uint32_t id = r2.y;
-            if (!is_tri) {
-                const uint4 r3 = r[3];
-                p11 = mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
-                id = r3.x;
-            }
-            if (COUNT) ctr->exact++;
-            float t, u, v;
-            if (intersect_patch(ray.o, ray.d, tmax, p00, p10, p01, p11, &t, &u, &v)) {
-                tmax = t; found = true; hit.prim_id = id; hit.t = t; hit.u = u; hit.v = v;
-                return true;
-            }
-            return false;
+        auto defer_prim = [&](uint32_t tagged_unit) {
+            if (d0 == PM_DEFER_NONE) d0 = tagged_unit;
+            else if (d1 == PM_DEFER_NONE) d1 = tagged_unit;
+            else if (d2 == PM_DEFER_NONE) d2 = tagged_unit;
+            else slow = true;
         };
 
-        // ---- spheres: pre-filter, deferred (a third sphere for the same ray is tested at once)
+        // ---- spheres: float pre-filter; what passes is deferred
         for (uint32_t i = 0; i < fs.n_sphere; ++i) {
             const uint32_t unit = as_uniform(fs.units)[i];
-            if (live && !(ANY && (found || sure))) {
+            if (live && !slow) {
                 if (COUNT) ctr->prims++;
-                bool now = defer_list == nullptr;
-                if (!now) {
-                    const cuint4_p r = as_uniform(prims + unit);
-                    float m[12];
-                    const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
-                    m[0] = __uint_as_float(r0.x); m[1] = __uint_as_float(r0.y); m[2] = __uint_as_float(r0.z); m[3] = __uint_as_float(r0.w);
-                    m[4] = __uint_as_float(r1.x); m[5] = __uint_as_float(r1.y); m[6] = __uint_as_float(r1.z); m[7] = __uint_as_float(r1.w);
-                    m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
-                    if (sphere_prefilter(ray.o, ray.d, R, D, m, __uint_as_float(r3.x), __uint_as_float(r4.z), __uint_as_float(r4.w), tcull)) {
-                        if (sph0 == 0xFFFFFFFFu) sph0 = unit;
-                        else if (sph1 == 0xFFFFFFFFu) sph1 = unit;
-                        else now = true;
-                    }
-                }
-                if (now) test_sphere_now(unit);
+                const cuint4_p r = as_uniform(prims + unit);
+                float m[12];
+                const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+                m[0] = __uint_as_float(r0.x); m[1] = __uint_as_float(r0.y); m[2] = __uint_as_float(r0.z); m[3] = __uint_as_float(r0.w);
+                m[4] = __uint_as_float(r1.x); m[5] = __uint_as_float(r1.y); m[6] = __uint_as_float(r1.z); m[7] = __uint_as_float(r1.w);
+                m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
+                if (sphere_prefilter(ray.o, ray.d, R, D, m, __uint_as_float(r3.x), __uint_as_float(r4.z), __uint_as_float(r4.w), tcull))
+                    defer_prim(unit);
             }
         }
-        // ---- patches: reference arithmetic at once
-        for (uint32_t i = 0; i < fs.n_patch; ++i) {
-            const uint32_t unit = as_uniform(fs.units)[fs.n_sphere + i];
-            if (live && !(ANY && (found || sure))) {
-                if (COUNT) ctr->prims++;
-                if (test_patch_now(unit, false)) tcull = fminf(tcull, hit.t);
+        // ---- patches (PATCH: the scene has some; kernels for scenes without are compiled without the bilinear patch test,
+        // whose registers would cost the sweep a wave per SIMD): reference arithmetic at once
+        if (PATCH) {
+            for (uint32_t i = 0; i < fs.n_patch; ++i) {
+                const uint32_t unit = as_uniform(fs.units)[fs.n_sphere + i];
+                if (live && !slow && !(ANY && found)) {
+                    if (COUNT) { ctr->prims++; ctr->exact++; }
+                    const cuint4_p r = as_uniform(prims + unit);
+                    const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+                    float t, u, v;
+                    if (intersect_patch(ray.o, ray.d, tmax, mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)),
+                                        mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y)),
+                                        mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x)),
+                                        mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w)), &t, &u, &v)) {
+                        tmax = t; tcull = fminf(tcull, t); found = true; hit.prim_id = r3.x; hit.t = t; hit.u = u; hit.v = v;
+                    }
+                }
             }
         }
         // ---- triangles: pre-filter, candidates queued for the exact round.  The culling distance becomes a fraction.
         FlatCull cull; cull.cn = tcull; cull.cd = 1.0f;
         const float KD = PM_PRE_K * D, R2 = 2.0f * R, epsb_ray = 8e-7f * __fmaf_rn(9.0f, R, D);
         for (uint32_t i = 0; i < fs.n_tri; ++i) {
-            if (ANY && !__any(live && !(found || sure))) break;
+            if (ANY && (i & 7u) == 0u && !__any(live && !slow && !(found || sure))) break;   // (closest hit: every live ray sweeps the whole table)
             const cuint4_p e = as_uniform(reinterpret_cast<const uint4*>(fs.tris + i));
             const uint4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3];
-            if (live && !(ANY && (found || sure))) {
+            if (live && !slow && !(ANY && (found || sure))) {
                 if (COUNT) ctr->prims++;
                 float ln, ld;
                 const int cls = tri_prefilter_flat(ray.o, ray.d, KD, R2,
@@ -794,31 +803,37 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
                                                    __uint_as_float(q0.w), __uint_as_float(q2.w), __uint_as_float(q3.w), epsb_ray,
                                                    &cull, !ANY, &ln, &ld);
                 if (cls != 0) {
-                    if (cls == 2) sure = true;
-                    if (qn < PM_CAND_MAX) {
+                    if (ANY && cls == 2) sure = true;       // (closest hit: read off the culling fraction after the loop)
+                    if (qn < PM_FLAT_CAND_MAX) {
                         cand[qn * stride] = q1.w;
-                        cand[(PM_CAND_MAX + qn) * stride] = __float_as_uint(ln);
-                        cand[(2 * PM_CAND_MAX + qn) * stride] = __float_as_uint(ld);
+                        cand[(PM_FLAT_CAND_MAX + qn) * stride] = __float_as_uint(ln);
+                        cand[(2 * PM_FLAT_CAND_MAX + qn) * stride] = __float_as_uint(ld);
                         ++qn;
-                    } else (void)test_patch_now(q1.w, true);    // queue full: exact test at once (does not lower the culling distance)
+                    } else slow = true;         // one candidate too many: the second pass redoes this ray exactly
                 }
             }
         }
+        // a certain hit always lowers the culling fraction of a closest-hit ray, so "was there one" need not be tracked in
+        // the loop (tracking it there costs a branchier loop body: measured 10 % of the kernel)
+        if (!ANY) sure = !(cull.cn == tcull && cull.cd == 1.0f);
         // ---- exact round: the queued triangles, in the order they were met, minus the certain hits whose t bracket starts
         // beyond the final culling distance (they lie behind another certain hit); compacted first so that the wave makes
         // as many trips as its busiest lane has survivors
         {
             uint32_t m = 0;
-            for (uint32_t qi = 0; qi < PM_CAND_MAX; ++qi) {
+            for (uint32_t qi = 0; qi < PM_FLAT_CAND_MAX; ++qi) {
                 if (qi >= qn) continue;
-                const float ln = __uint_as_float(cand[(PM_CAND_MAX + qi) * stride]), ld = __uint_as_float(cand[(2 * PM_CAND_MAX + qi) * stride]);
+                const float ln = __uint_as_float(cand[(PM_FLAT_CAND_MAX + qi) * stride]), ld = __uint_as_float(cand[(2 * PM_FLAT_CAND_MAX + qi) * stride]);
                 if (!(ln * cull.cd > cull.cn * ld)) { cand[m * stride] = cand[qi * stride]; ++m; }
             }
             qn = m;
         }
-        for (uint32_t qi = 0; qi < PM_CAND_MAX; ++qi) {
-            if (!__any(live && qi < qn && !(ANY && found))) break;
-            if (live && qi < qn && !(ANY && found)) {
+        // what the closest hit must not exceed if culling was right: the fraction as a float, rounded DOWN (one value
+        // kept across the exact round instead of two)
+        const float tconf = fdn(cull.cn / cull.cd);
+        for (uint32_t qi = 0; qi < PM_FLAT_CAND_MAX; ++qi) {
+            if (!__any(live && !slow && qi < qn && !(ANY && found))) break;
+            if (live && !slow && qi < qn && !(ANY && found)) {
                 const uint4* r = prims + cand[qi * stride];
                 const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
                 const f3 v0 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
@@ -831,44 +846,79 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
                 }
             }
         }
-        // ---- did the exact tests confirm what culling assumed?  If not: everything again, exactly (counted; never seen)
-        const bool redo = live && sure && !(found && (ANY || !(hit.t * cull.cd > cull.cn)));
-        if (__any(redo)) {
-            if (redo) {
-                if (COUNT) ctr->fallback++;
-                tmax = ray.tmax; found = false; sph0 = 0xFFFFFFFFu; sph1 = 0xFFFFFFFFu;
-                hit.prim_id = 0xFFFFFFFFu; hit.t = ray.tmax; hit.u = 0.0f; hit.v = 0.0f;
-            }
-            for (uint32_t i = 0; i < fs.n_sphere; ++i) {
-                const uint32_t unit = fs.units[i];
-                if (redo && !(ANY && found)) { if (COUNT) ctr->prims++; test_sphere_now(unit); }
-            }
-            for (uint32_t i = 0; i < fs.n_patch; ++i) {
-                const uint32_t unit = fs.units[fs.n_sphere + i];
-                if (redo && !(ANY && found)) { if (COUNT) ctr->prims++; (void)test_patch_now(unit, false); }
-            }
-            for (uint32_t i = 0; i < fs.n_tri; ++i) {
-                const uint32_t unit = fs.tris[i].unit;
-                if (redo && !(ANY && found)) { if (COUNT) ctr->prims++; (void)test_patch_now(unit, true); }
-            }
-        }
-        // ---- commit; rays with deferred spheres go to the second pass (see trace_persistent)
-        const bool defer = live && sph0 != 0xFFFFFFFFu && !(ANY && found);
-        if (live && (!ANY || !defer)) commit(item, found, hit);
-        if (defer_list != nullptr) dw.push(defer, lane, item, sph0, sph1);
+        // ---- did the exact tests confirm what culling assumed?  If not the ray is slow too (counted; never seen)
+        const bool unconfirmed = live && !slow && sure && !(found && (ANY || hit.t <= tconf));
+        if (COUNT && unconfirmed) ctr->fallback++;
+        // ---- commit.  Closest hit: what the triangles gave is committed now and the second pass improves it with the
+        // deferred primitives.  Any hit: a ray occluded by a triangle is final; one with deferred primitives is committed by
+        // the second pass.  Slow rays are committed by the second pass alone.
+        const bool redo = live && (slow || unconfirmed);
+        const bool pass2 = live && !redo && d0 != PM_DEFER_NONE && !(ANY && found);
+        if (live && !redo && (!ANY || !pass2)) commit(item, found, hit);
+        dw.push(pass2, lane, item, d0, d1, d2);
+        sw.push(redo, lane, item);
     }
-    if (defer_list != nullptr) dw.pad(lane);
+    dw.pad(lane);
+    sw.pad(lane);
 }
 
-// Second pass over the (work item, sphere, sphere) entries that trace_persistent deferred: every lane runs the exact
-// interval test, so the waves of this pass are dense.  Closest hit: the entry's ray already has its best non-deferred hit
-// committed; load_t(i) returns that t and commit(i, true, hit) overwrites it when a sphere is nearer.  Any hit: the ray was
-// not occluded by anything else and has not been committed; commit(i, occluded, .) finishes it.
-// The list has holes (the padding of the waves' reservations), so a wave first gathers valid entries into `buf` (LDS,
-// 128 entries per wave) and runs the tests on 64 of them at a time.
+// exact tests of the second pass: a hit lowers *tmax and replaces *hit
+template <bool COUNT>
+PMD void fix_test_sphere(const uint4* __restrict__ prims, uint32_t unit, const Ray& ray, float* tmax, bool* found, HitRec* hit,
+                         TravCounters* ctr) {
+    const uint4* r = prims + unit;
+    float m[12];
+    const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+    m[0] = __uint_as_float(r0.x); m[1] = __uint_as_float(r0.y); m[2] = __uint_as_float(r0.z); m[3] = __uint_as_float(r0.w);
+    m[4] = __uint_as_float(r1.x); m[5] = __uint_as_float(r1.y); m[6] = __uint_as_float(r1.z); m[7] = __uint_as_float(r1.w);
+    m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
+    const float radius = __uint_as_float(r3.x), zmin = __uint_as_float(r3.y), zmax = __uint_as_float(r3.z), phimax = __uint_as_float(r3.w);
+    if (COUNT) ctr->exact++;
+    SphereHit sh;
+    if (intersect_sphere(ray.o, ray.d, *tmax, m, radius, zmin, zmax, phimax, &sh)) {
+        *tmax = sh.t; *found = true; hit->prim_id = r4.x; hit->t = sh.t;
+        // (u,v) of sphere.rs:382-385
+        const float th0 = acosf(fminf(fmaxf(zmin / radius, -1.0f), 1.0f));
+        const float th1 = acosf(fminf(fmaxf(zmax / radius, -1.0f), 1.0f));
+        const float th = acosf(fminf(fmaxf(sh.p_obj.z / radius, -1.0f), 1.0f));
+        hit->u = sh.phi / phimax; hit->v = (th - th0) / (th1 - th0);
+    }
+}
+template <bool COUNT>
+PMD void fix_test_patch(const uint4* __restrict__ prims, uint32_t unit, bool is_tri, const Ray& ray, float* tmax, bool* found,
+                        HitRec* hit, TravCounters* ctr) {
+    const uint4* r = prims + unit;
+    const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
+    const f3 p00 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
+    const f3 p10 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
+    const f3 p01 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
+    f3 p11 = p01;
+    uint32_t id = r2.y;
+    if (!is_tri) {
+        const uint4 r3 = r[3];
+        p11 = mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
+        id = r3.x;
+    }
+    if (COUNT) ctr->exact++;
+    float t, u, v;
+    if (intersect_patch(ray.o, ray.d, *tmax, p00, p10, p01, p11, &t, &u, &v)) {
+        *tmax = t; *found = true; hit->prim_id = id; hit->t = t; hit->u = u; hit->v = v;
+    }
+}
+
+// Second pass over the list entries {work item, unit, unit, unit}: every lane runs exact tests, so the waves of this pass
+// are dense.  The list has holes (the padding of the waves' reservations), so a wave first gathers valid entries into
+// `buf` (LDS, 128 entries per wave) and works on 64 of them at a time.  The units are spheres / patches (PM_DEFER_PATCH)
+// deferred for this ray.  Closest hit: the ray already has its best other hit committed; load_t(i) returns that t and
+// commit(i, true, hit) overwrites it when a deferred primitive is nearer.  Any hit: nothing else occluded the ray and it
+// has not been committed; commit(i, occluded, .).
+// Then (flat sweep only) the slow list: those rays are redone from scratch, every primitive of the flat table through its
+// exact test, and committed whatever the outcome.
 template <bool ANY, bool COUNT, class FetchFn, class LoadTFn, class CommitFn>
-PMD void sphere_fix(const uint4* __restrict__ prims, const uint4* __restrict__ defer_list, const uint32_t* __restrict__ defer_count,
-                    uint4* buf, TravCounters* ctr, FetchFn fetch, LoadTFn load_t, CommitFn commit) {
+PMD void deferred_fix(FlatScene fs, const uint4* __restrict__ prims, const uint4* __restrict__ defer_list,
+                      const uint32_t* __restrict__ defer_count, const uint32_t* __restrict__ slow_list,
+                      const uint32_t* __restrict__ slow_count, uint4* buf, TravCounters* ctr, FetchFn fetch, LoadTFn load_t,
+                      CommitFn commit) {
     const uint32_t n = *defer_count;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -892,33 +942,73 @@ PMD void sphere_fix(const uint4* __restrict__ prims, const uint4* __restrict__ d
         if (64u + lane < cnt) buf[lane] = tail;
         cnt -= take;
         __threadfence_block();
-        Ray ray;
-        if (ent.x == 0xFFFFFFFFu || !fetch(ent.x, &ray)) continue;
-        float tmax = ANY ? ray.tmax : load_t(ent.x);
+        Ray ray; ray.o = mk3(0.f, 0.f, 0.f); ray.d = mk3(0.f, 0.f, 1.f); ray.tmax = 0.f;
+        const bool have = ent.x != 0xFFFFFFFFu && fetch(ent.x, &ray);
+        float tmax = ray.tmax;
+        if (have && !ANY) tmax = load_t(ent.x);
         bool found = false;
         HitRec hit; hit.prim_id = 0xFFFFFFFFu; hit.t = tmax; hit.u = 0.0f; hit.v = 0.0f;
-        for (int k = 0; k < 2; ++k) {
-            const uint32_t unit = k ? ent.z : ent.y;
-            if (unit == 0xFFFFFFFFu || (ANY && found)) continue;
-            const uint4* r = prims + unit;
-            float m[12];
-            const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
-            m[0] = __uint_as_float(r0.x); m[1] = __uint_as_float(r0.y); m[2] = __uint_as_float(r0.z); m[3] = __uint_as_float(r0.w);
-            m[4] = __uint_as_float(r1.x); m[5] = __uint_as_float(r1.y); m[6] = __uint_as_float(r1.z); m[7] = __uint_as_float(r1.w);
-            m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
-            const float radius = __uint_as_float(r3.x), zmin = __uint_as_float(r3.y), zmax = __uint_as_float(r3.z),
-                        phimax = __uint_as_float(r3.w);
-            if (COUNT) ctr->exact++;
-            SphereHit sh;
-            if (intersect_sphere(ray.o, ray.d, tmax, m, radius, zmin, zmax, phimax, &sh)) {
-                tmax = sh.t; found = true; hit.prim_id = r4.x; hit.t = sh.t;
-                const float th0 = acosf(fminf(fmaxf(zmin / radius, -1.0f), 1.0f));
-                const float th1 = acosf(fminf(fmaxf(zmax / radius, -1.0f), 1.0f));
-                const float th = acosf(fminf(fmaxf(sh.p_obj.z / radius, -1.0f), 1.0f));
-                hit.u = sh.phi / phimax; hit.v = (th - th0) / (th1 - th0);
+        // ---- the deferred spheres / patches of this ray
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t tagged = k == 0 ? ent.y : (k == 1 ? ent.z : ent.w);
+            if (!have || tagged == PM_DEFER_NONE || (ANY && found)) continue;
+            if (tagged & PM_DEFER_PATCH) fix_test_patch<COUNT>(prims, tagged & ~PM_DEFER_PATCH, false, ray, &tmax, &found, &hit, ctr);
+            else fix_test_sphere<COUNT>(prims, tagged, ray, &tmax, &found, &hit, ctr);
+        }
+        if (have && (ANY || found)) commit(ent.x, found, hit);
+    }
+    // ---- slow rays (flat sweep only): everything, exactly.  Same gathering, in the first 128 words of buf.
+    if (slow_list == nullptr) return;
+    const uint32_t ns = *slow_count;
+    uint32_t* ibuf = reinterpret_cast<uint32_t*>(buf);
+    cnt = 0;
+    for (uint32_t base = wave * 64u; base < ns || cnt > 0u; base += n_waves * 64u) {
+        if (base < ns) {
+            uint32_t it = 0xFFFFFFFFu;
+            if (base + lane < ns) it = slow_list[base + lane];
+            const bool valid = it != 0xFFFFFFFFu;
+            const unsigned long long vm = __ballot(valid);
+            if (valid) ibuf[cnt + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull))] = it;
+            cnt += (uint32_t)__popcll(vm);
+            __threadfence_block();
+            if (cnt < 64u && base + n_waves * 64u < ns) continue;
+        }
+        const uint32_t take = cnt < 64u ? cnt : 64u;
+        uint32_t it = 0xFFFFFFFFu, tail = 0xFFFFFFFFu;
+        if (lane < take) it = ibuf[lane];
+        if (64u + lane < cnt) tail = ibuf[64u + lane];
+        __threadfence_block();
+        if (64u + lane < cnt) ibuf[lane] = tail;
+        cnt -= take;
+        __threadfence_block();
+        Ray ray; ray.o = mk3(0.f, 0.f, 0.f); ray.d = mk3(0.f, 0.f, 1.f); ray.tmax = 0.f;
+        const bool have = it != 0xFFFFFFFFu && fetch(it, &ray);
+        float tmax = ray.tmax;
+        bool found = false;
+        HitRec hit; hit.prim_id = 0xFFFFFFFFu; hit.t = tmax; hit.u = 0.0f; hit.v = 0.0f;
+        for (uint32_t i = 0; i < fs.n_sphere; ++i) {
+            const uint32_t unit = fs.units[i];
+            if (have && !(ANY && found)) { if (COUNT) ctr->prims++; fix_test_sphere<COUNT>(prims, unit, ray, &tmax, &found, &hit, ctr); }
+        }
+        for (uint32_t i = 0; i < fs.n_patch; ++i) {
+            const uint32_t unit = fs.units[fs.n_sphere + i];
+            if (have && !(ANY && found)) { if (COUNT) ctr->prims++; fix_test_patch<COUNT>(prims, unit, false, ray, &tmax, &found, &hit, ctr); }
+        }
+        for (uint32_t i = 0; i < fs.n_tri; ++i) {
+            const uint32_t unit = fs.tris[i].unit;
+            if (have && !(ANY && found)) {
+                if (COUNT) { ctr->prims++; ctr->exact++; }
+                const uint4* r = prims + unit;
+                const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
+                float t, u, v;
+                if (intersect_tri_exact(ray.o, ray.d, tmax, mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)),
+                                        mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y)),
+                                        mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x)), &t, &u, &v)) {
+                    tmax = t; found = true; hit.prim_id = r2.y; hit.t = t; hit.u = u; hit.v = v;
+                }
             }
         }
-        if (ANY || found) commit(ent.x, found, hit);
+        if (have) commit(it, found, hit);
     }
 }
 

@@ -156,11 +156,12 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR void shadow_kernel(SceneArrays sc,
     if (tc.overflow) atomicAdd(&counters[3], 1ull);
 }
 // flat-sweep variants for scenes of at most PM_FLAT_MAX_PRIMS primitives (pm_device.hpp trace_flat)
-template <bool COUNT>
+template <bool COUNT, bool PATCH>
 __global__ __launch_bounds__(TB) PM_FLAT_ATTR void closest_flat_kernel(PmFlatScene fs, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
                                                           const uint32_t* __restrict__ count, uint4* __restrict__ defer_list,
-                                                          uint32_t* __restrict__ defer_count, unsigned long long* __restrict__ counters) {
-    __shared__ uint32_t cand[3 * PM_CAND_MAX * TB];     // units, then the lower bounds of t as fractions (numerators, denominators)
+                                                          uint32_t* __restrict__ defer_count, uint32_t* __restrict__ slow_list,
+                                                          unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t cand[3 * PM_FLAT_CAND_MAX * TB];     // units, then the lower bounds of t as fractions (numerators, denominators)
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
         const uint32_t slot = queue[i];
@@ -173,17 +174,18 @@ __global__ __launch_bounds__(TB) PM_FLAT_ATTR void closest_flat_kernel(PmFlatSce
     auto commit = [&](uint32_t i, bool found, const HitRec& h) {
         pa.hit[queue[i]] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
     };
-    trace_flat<false, COUNT>(fs, sc.prims, *count, cand + threadIdx.x, TB, defer_list, defer_count, &tc, fetch, commit);
+    trace_flat<false, COUNT, PATCH>(fs, sc.prims, *count, cand + threadIdx.x, TB, defer_list, defer_count, slow_list,
+                             defer_count + PM_WORK_SLOTS, &tc, fetch, commit);
     if (COUNT) {
         atomicAdd(&counters[2], (unsigned long long)tc.prims); atomicAdd(&counters[6], (unsigned long long)tc.exact);
         if (tc.fallback) atomicAdd(&counters[7], (unsigned long long)tc.fallback);
     }
 }
-template <bool COUNT>
+template <bool COUNT, bool PATCH>
 __global__ __launch_bounds__(TB) PM_FLAT_ATTR void shadow_flat_kernel(PmFlatScene fs, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ count,
                                                          uint4* __restrict__ defer_list, uint32_t* __restrict__ defer_count,
-                                                         unsigned long long* __restrict__ counters) {
-    __shared__ uint32_t cand[3 * PM_CAND_MAX * TB];     // units, then the lower bounds of t as fractions (numerators, denominators)
+                                                         uint32_t* __restrict__ slow_list, unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t cand[3 * PM_FLAT_CAND_MAX * TB];     // units, then the lower bounds of t as fractions (numerators, denominators)
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
         const uint32_t slot = pa.shq[i];
@@ -200,17 +202,18 @@ __global__ __launch_bounds__(TB) PM_FLAT_ATTR void shadow_flat_kernel(PmFlatScen
             pa.L[slot] = L;
         }
     };
-    trace_flat<true, COUNT>(fs, sc.prims, *count, cand + threadIdx.x, TB, defer_list, defer_count, &tc, fetch, commit);
+    trace_flat<true, COUNT, PATCH>(fs, sc.prims, *count, cand + threadIdx.x, TB, defer_list, defer_count, slow_list,
+                            defer_count + PM_WORK_SLOTS, &tc, fetch, commit);
     if (COUNT) {
         atomicAdd(&counters[5], (unsigned long long)tc.prims); atomicAdd(&counters[6], (unsigned long long)tc.exact);
         if (tc.fallback) atomicAdd(&counters[7], (unsigned long long)tc.fallback);
     }
 }
-// exact tests of the spheres the kernels above deferred (pm_device.hpp sphere_fix), with the same fetch / commit
+// second pass (pm_device.hpp deferred_fix): exact tests of what the kernels above deferred, with the same fetch / commit
 template <bool COUNT>
-__global__ __launch_bounds__(TB) void closest_fix_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(TB) void closest_fix_kernel(PmFlatScene fs, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
                                                          const uint4* __restrict__ defer_list, const uint32_t* __restrict__ defer_count,
-                                                         unsigned long long* __restrict__ counters) {
+                                                         const uint32_t* __restrict__ slow_list, unsigned long long* __restrict__ counters) {
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
         const uint32_t slot = queue[i];
@@ -223,12 +226,14 @@ __global__ __launch_bounds__(TB) void closest_fix_kernel(SceneArrays sc, PathArr
         pa.hit[queue[i]] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
     };
     __shared__ uint4 gather[128 * (TB / 64)];
-    sphere_fix<false, COUNT>(sc.prims, defer_list, defer_count, gather + 128 * (threadIdx.x >> 6), &tc, fetch, load_t, commit);
+    deferred_fix<false, COUNT>(fs, sc.prims, defer_list, defer_count, slow_list, defer_count + PM_WORK_SLOTS,
+                               gather + 128 * (threadIdx.x >> 6), &tc, fetch, load_t, commit);
     if (COUNT && tc.exact) atomicAdd(&counters[6], (unsigned long long)tc.exact);
+    if (COUNT && tc.prims) atomicAdd(&counters[2], (unsigned long long)tc.prims);
 }
 template <bool COUNT>
-__global__ __launch_bounds__(TB) void shadow_fix_kernel(SceneArrays sc, PathArrays pa, const uint4* __restrict__ defer_list,
-                                                        const uint32_t* __restrict__ defer_count,
+__global__ __launch_bounds__(TB) void shadow_fix_kernel(PmFlatScene fs, SceneArrays sc, PathArrays pa, const uint4* __restrict__ defer_list,
+                                                        const uint32_t* __restrict__ defer_count, const uint32_t* __restrict__ slow_list,
                                                         unsigned long long* __restrict__ counters) {
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
@@ -248,8 +253,10 @@ __global__ __launch_bounds__(TB) void shadow_fix_kernel(SceneArrays sc, PathArra
         }
     };
     __shared__ uint4 gather[128 * (TB / 64)];
-    sphere_fix<true, COUNT>(sc.prims, defer_list, defer_count, gather + 128 * (threadIdx.x >> 6), &tc, fetch, load_t, commit);
+    deferred_fix<true, COUNT>(fs, sc.prims, defer_list, defer_count, slow_list, defer_count + PM_WORK_SLOTS,
+                              gather + 128 * (threadIdx.x >> 6), &tc, fetch, load_t, commit);
     if (COUNT && tc.exact) atomicAdd(&counters[6], (unsigned long long)tc.exact);
+    if (COUNT && tc.prims) atomicAdd(&counters[5], (unsigned long long)tc.prims);
 }
 
 // ------------------------------------------------------------------------------------------ shade
@@ -925,33 +932,34 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
         rc.s_base = sb; rc.s_count = std::min(s_per_pass, s1 - sb);
         const uint32_t npaths = (uint32_t)(npix_pad * (size_t)rc.s_count);
         HIPCHK(c, hipMemsetAsync(pa.counts, 0, 2 * (size_t)nb * 4, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_work, 0, 2 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_work, 0, 3 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
         int wslot = 0;      // one work counter per traversal launch (re-zeroed when the slots run out)
         const dim3 gr((npaths + RB - 1) / RB);
         const dim3 gt(std::min<uint32_t>((npaths + TB - 1) / TB, (uint32_t)c->n_cu * PM_BLOCKS_PER_CU));
         const dim3 gf(std::min<uint32_t>((npaths + TB - 1) / TB, (uint32_t)c->n_cu * PM_FLAT_BLOCKS_PER_CU));
-        const bool flat = c->flat.tris != nullptr;
+        const bool flat = c->flat.tris != nullptr, fpatch = c->flat.n_patch > 0;
         mark(0);
         hipLaunchKernelGGL(raygen_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, npaths);
         uint32_t *qin = pa.q0, *qout = pa.q1;
         for (int b = 0; b <= p->max_depth; ++b) {
             uint32_t* cnt_in = pa.counts + b; uint32_t* cnt_out = pa.counts + b + 1; uint32_t* cnt_sh = pa.counts + nb + b;
             if (wslot + 2 > PM_WORK_SLOTS) {   // stream-ordered: every earlier traversal kernel has finished with its counter
-                HIPCHK(c, hipMemsetAsync(c->d_work, 0, 2 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
+                HIPCHK(c, hipMemsetAsync(c->d_work, 0, 3 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
                 wslot = 0;
             }
             mark(1);
             if (flat) {
-                if (c->counting) hipLaunchKernelGGL(closest_flat_kernel<true>, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, qin, cnt_in, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_counters);
-                else hipLaunchKernelGGL(closest_flat_kernel<false>, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, qin, cnt_in, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_counters);
+                auto kernel = c->counting ? (fpatch ? closest_flat_kernel<true, true> : closest_flat_kernel<true, false>)
+                                          : (fpatch ? closest_flat_kernel<false, true> : closest_flat_kernel<false, false>);
+                hipLaunchKernelGGL(kernel, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, qin, cnt_in, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_slow, c->d_counters);
             } else {
                 auto kernel = c->counting ? (has_spheres ? closest_kernel<true, true> : closest_kernel<true, false>)
                                           : (has_spheres ? closest_kernel<false, true> : closest_kernel<false, false>);
                 hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_work + wslot, c->refill, c->d_defer, c->d_counters);
             }
-            if (has_spheres) {     // dense exact tests of the deferred spheres (timed with the closest-hit class)
-                if (c->counting) hipLaunchKernelGGL(closest_fix_kernel<true>, gt, dim3(TB), 0, c->stream, sa, pa, qin, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_counters);
-                else hipLaunchKernelGGL(closest_fix_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, qin, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_counters);
+            if (has_spheres || flat) {     // second pass: dense exact tests of what was deferred (timed with the closest-hit class)
+                if (c->counting) hipLaunchKernelGGL(closest_fix_kernel<true>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, qin, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
+                else hipLaunchKernelGGL(closest_fix_kernel<false>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, qin, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
             }
             ++wslot;
             mark(2);
@@ -960,16 +968,17 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
             if (!random_walk && p->sample_lights && b < p->max_depth) {
                 mark(3);
                 if (flat) {
-                    if (c->counting) hipLaunchKernelGGL(shadow_flat_kernel<true>, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, cnt_sh, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_counters);
-                    else hipLaunchKernelGGL(shadow_flat_kernel<false>, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, cnt_sh, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_counters);
+                    auto kernel = c->counting ? (fpatch ? shadow_flat_kernel<true, true> : shadow_flat_kernel<true, false>)
+                                              : (fpatch ? shadow_flat_kernel<false, true> : shadow_flat_kernel<false, false>);
+                    hipLaunchKernelGGL(kernel, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, cnt_sh, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_slow, c->d_counters);
                 } else {
                     auto kernel = c->counting ? (has_spheres ? shadow_kernel<true, true> : shadow_kernel<true, false>)
                                               : (has_spheres ? shadow_kernel<false, true> : shadow_kernel<false, false>);
                     hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_work + wslot, c->refill, c->d_defer, c->d_counters);
                 }
-                if (has_spheres) {
-                    if (c->counting) hipLaunchKernelGGL(shadow_fix_kernel<true>, gt, dim3(TB), 0, c->stream, sa, pa, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_counters);
-                    else hipLaunchKernelGGL(shadow_fix_kernel<false>, gt, dim3(TB), 0, c->stream, sa, pa, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_counters);
+                if (has_spheres || flat) {
+                    if (c->counting) hipLaunchKernelGGL(shadow_fix_kernel<true>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
+                    else hipLaunchKernelGGL(shadow_fix_kernel<false>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
                 }
                 ++wslot;
             }
