@@ -789,6 +789,9 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
         FlatCull cull; cull.cn = tcull; cull.cd = 1.0f;
         const float KD = PM_PRE_K * D, R2 = 2.0f * R, epsb_ray = 8e-7f * __fmaf_rn(9.0f, R, D);
         for (uint32_t i = 0; i < fs.n_tri; ++i) {
+            // a certain hit always lowers the culling fraction, so "was there one" is read off it instead of being tracked
+            // (tracking it makes the loop body branchier: measured 10 % of the kernel)
+            if (ANY) sure = !(cull.cn == tcull && cull.cd == 1.0f);
             if (ANY && (i & 7u) == 0u && !__any(live && !slow && !(found || sure))) break;   // (closest hit: every live ray sweeps the whole table)
             const cuint4_p e = as_uniform(reinterpret_cast<const uint4*>(fs.tris + i));
             const uint4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3];
@@ -801,9 +804,8 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
                                                    mk3(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z)),
                                                    mk3(__uint_as_float(q3.x), __uint_as_float(q3.y), __uint_as_float(q3.z)),
                                                    __uint_as_float(q0.w), __uint_as_float(q2.w), __uint_as_float(q3.w), epsb_ray,
-                                                   &cull, !ANY, &ln, &ld);
+                                                   &cull, true, &ln, &ld);
                 if (cls != 0) {
-                    if (ANY && cls == 2) sure = true;       // (closest hit: read off the culling fraction after the loop)
                     if (qn < PM_FLAT_CAND_MAX) {
                         cand[qn * stride] = q1.w;
                         cand[(PM_FLAT_CAND_MAX + qn) * stride] = __float_as_uint(ln);
@@ -813,9 +815,7 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
                 }
             }
         }
-        // a certain hit always lowers the culling fraction of a closest-hit ray, so "was there one" need not be tracked in
-        // the loop (tracking it there costs a branchier loop body: measured 10 % of the kernel)
-        if (!ANY) sure = !(cull.cn == tcull && cull.cd == 1.0f);
+        sure = !(cull.cn == tcull && cull.cd == 1.0f);
         // ---- exact round: the queued triangles, in the order they were met, minus the certain hits whose t bracket starts
         // beyond the final culling distance (they lie behind another certain hit); compacted first so that the wave makes
         // as many trips as its busiest lane has survivors
