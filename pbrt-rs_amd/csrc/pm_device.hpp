@@ -453,7 +453,12 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
     bool ngx = false, ngy = false, ngz = false;
     uint32_t oct = 0;
     float R = 0.f, D = 0.f, tmax = 0.f, tcull = 0.f;
-    bool sure = false, found = false, exact_mode = false;
+    bool found = false, exact_mode = false;
+    // "a certain triangle hit was claimed": closest-hit walks do not track it - such a claim always lowers tcull below
+    // ray.tmax (and when an exact sphere / patch hit lowered it instead, the confirmation below holds trivially); measured
+    // +6 % on C3.  Any-hit walks test it at every step, so they keep the flag (measured).
+    bool sure_any = false;
+#define PM_SURE (ANY ? sure_any : (tcull < ray.tmax))
     uint32_t qn = 0;
     uint32_t sph0 = 0xFFFFFFFFu, sph1 = 0xFFFFFFFFu;      // spheres that passed the pre-filter (deferred to sphere_fix)
     int sp = 0;
@@ -462,7 +467,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
     uint2 spill[PM_SPILL_STACK];
 
     auto start_walk = [&]() {
-        tmax = ray.tmax; tcull = ray.tmax; sure = false; found = false; qn = 0; sp = 0; steps = 0;
+        tmax = ray.tmax; tcull = ray.tmax; sure_any = false; found = false; qn = 0; sp = 0; steps = 0;
         sph0 = 0xFFFFFFFFu; sph1 = 0xFFFFFFFFu;
         hit.prim_id = 0xFFFFFFFFu; hit.t = ray.tmax; hit.u = 0.0f; hit.v = 0.0f;
         cur = make_uint2(0u, (1u << 8) | perm8(1u, oct));     // pseudo group holding only the root
@@ -498,7 +503,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                 }
                 finished = false;
                 // did the exact tests confirm what culling assumed?
-                const bool confirmed = !sure || (found && (ANY || hit.t <= tcull));
+                const bool confirmed = !PM_SURE || (found && (ANY || hit.t <= tcull));
                 if (confirmed || exact_mode) {
                     // closest hit: commit what the walk found, sphere_fix improves it; any hit: an occluded ray needs no
                     // sphere test, an unoccluded one is committed by sphere_fix
@@ -549,7 +554,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
         }
         if (active) {
             // ---- one node step (the pop of an exhausted group is merged into it)
-            bool ended = (ANY && (found || sure)) || ++steps > PM_WALK_GUARD;
+            bool ended = (ANY && (found || PM_SURE)) || ++steps > PM_WALK_GUARD;
             uint32_t pm = cur.y & 0xFFu;
             if (!ended && pm == 0u) {
                 if (sp == 0) ended = true;
@@ -611,13 +616,13 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                 const uint32_t ptype = n1.y >> 30;
                 const uint32_t pbase = n1.y & 0x3FFFFFFFu;
                 const uint32_t metaw[2] = {n1.z, n1.w};
-                while (lm && !(ANY && (found || sure))) {
+                while (lm && !(ANY && (found || PM_SURE))) {
                     const uint32_t kl = __ffs(lm) - 1u;
                     lm &= lm - 1u;
                     const uint32_t ls = kl ^ oct;
                     const uint32_t meta = (metaw[ls >> 2] >> (8 * (ls & 3))) & 0xFFu;
                     const uint32_t cnt = meta >> 5, off = meta & 31u;
-                    for (uint32_t j = 0; j < cnt && !(ANY && (found || sure)); ++j) {
+                    for (uint32_t j = 0; j < cnt && !(ANY && (found || PM_SURE)); ++j) {
                         if (COUNT) ctr->prims++;
                         if (ptype == PM_PRIM_SPHERE) {
                             const uint4* r = prims + pbase + (off + j) * PM_UNITS_SPHERE;
@@ -660,7 +665,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                                 const int cls = tri_prefilter(ray.o, ray.d, R, D, p00, p10, p01, tcull, &th, &tl);
                                 if (cls == 0) immediate = false;
                                 else {
-                                    if (cls == 2) { sure = true; if (!ANY) tcull = th; }
+                                    if (cls == 2) { if (ANY) sure_any = true; else tcull = th; }
                                     if (qn < PM_CAND_MAX) {
                                         cand[qn * stride] = unit; cand[(PM_CAND_MAX + qn) * stride] = __float_as_uint(tl);
                                         ++qn; immediate = false;
@@ -691,6 +696,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
         }
     }
 }
+#undef PM_SURE
 
 // ---- scenes of at most PM_FLAT_MAX_PRIMS primitives: no tree.  Every wave takes 64 consecutive work items and sweeps the
 // whole flat table (pm_layout.h) in lock step: the records are wave-uniform (scalar loads), nothing diverges but the
