@@ -6,7 +6,7 @@
 #include "pm_device.hpp"
 
 // ------------------------------------------------------------------------------------------ kernels
-template <bool ANY, bool COUNT, bool SPH>
+template <bool ANY, bool COUNT, bool MIXED>
 __global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR void trace_kernel(const PmWideNode* __restrict__ nodes,
                                                             const uint4* __restrict__ prims,
                                                             const PmRay* __restrict__ rays, uint32_t n,
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR void trace_kernel(const P
             *reinterpret_cast<float4*>(hits + i) = o;
         }
     };
-    pmd::trace_persistent<ANY, COUNT, SPH>(nodes, prims, n, work, refill, stack + threadIdx.x, cand + threadIdx.x, TRACE_BLOCK,
+    pmd::trace_persistent<ANY, COUNT, MIXED>(nodes, prims, n, work, refill, stack + threadIdx.x, cand + threadIdx.x, TRACE_BLOCK,
                                       defer_list, work + PM_WORK_SLOTS, &tc, fetch, commit);
     if (COUNT) {
         // wave-level reduction, one atomic per wave per counter
@@ -375,8 +375,9 @@ static int trace_impl(pm_ctx* c, const PmRay* rays, uint64_t n, void* out, size_
             hipLaunchKernelGGL(kernel, dim3(fgrid), dim3(TRACE_BLOCK), 0, c->stream, c->flat, c->d_prims, d_rays + b, m, oh, oo,
                                c->d_defer, c->d_work + PM_WORK_SLOTS + slot, c->d_slow, c->d_counters);
         } else {
-            auto kernel = c->counting ? (has_spheres ? trace_kernel<ANY, true, true> : trace_kernel<ANY, true, false>)
-                                      : (has_spheres ? trace_kernel<ANY, false, true> : trace_kernel<ANY, false, false>);
+            const bool mixed = has_spheres || !c->scene.patches.empty();
+            auto kernel = c->counting ? (mixed ? trace_kernel<ANY, true, true> : trace_kernel<ANY, true, false>)
+                                      : (mixed ? trace_kernel<ANY, false, true> : trace_kernel<ANY, false, false>);
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_nodes, c->d_prims, d_rays + b, m, oh, oo,
                                c->d_work + slot, c->refill, c->d_defer, c->d_counters);
         }

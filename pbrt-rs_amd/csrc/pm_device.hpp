@@ -431,13 +431,14 @@ PMD float safe_rcp_dir(float d) { return fabsf(d) < 1e-18f ? copysignf(1e18f, d)
 // assumed (it would take an error-analysis failure; counted in fallback), the ray is walked again with immediate exact
 // tests, so results are exact regardless.
 //
-// SPH: the scene holds spheres; those that pass sphere_prefilter are deferred to defer_list (kernels for scenes without
-// spheres are compiled without any of that: it costs registers, i.e. occupancy).
+// MIXED: the scene holds spheres and / or patches; spheres that pass sphere_prefilter are deferred to defer_list, patches
+// get the bilinear test at once.  Kernels for triangle-only scenes are compiled without any of that: it costs registers,
+// i.e. occupancy (and spills inside the 4-waves-per-SIMD cap).
 //   fetch(i, &ray) -> bool   load work item i (false: nothing to trace for it)
 //   commit(i, found, hit)    store the result of work item i
 // `lds` is this lane's column of the per-block LDS stack (entry e at lds[e * stride]); `cand` this lane's column of the
 // candidate queue.
-template <bool ANY, bool COUNT, bool SPH, class FetchFn, class CommitFn>
+template <bool ANY, bool COUNT, bool MIXED, class FetchFn, class CommitFn>
 PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __restrict__ prims, uint32_t n_items,
                           uint32_t* __restrict__ work_counter, uint32_t refill, uint2* lds, uint32_t* cand, int stride,
                           uint4* __restrict__ defer_list, uint32_t* __restrict__ defer_count,
@@ -507,11 +508,11 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                 if (confirmed || exact_mode) {
                     // closest hit: commit what the walk found, sphere_fix improves it; any hit: an occluded ray needs no
                     // sphere test, an unoccluded one is committed by sphere_fix
-                    defer = SPH && sph0 != 0xFFFFFFFFu && !(ANY && found);
+                    defer = MIXED && sph0 != 0xFFFFFFFFu && !(ANY && found);
                     if (!ANY || !defer) commit(item, found, hit);
                 } else { exact_mode = true; if (COUNT) ctr->fallback++; start_walk(); }
             }
-            if (SPH) dw.push(defer, lane, item, sph0, sph1, 0xFFFFFFFFu);      // wave-uniform control flow here
+            if (MIXED) dw.push(defer, lane, item, sph0, sph1, 0xFFFFFFFFu);      // wave-uniform control flow here
             // ---- idle lanes fetch the next items
             if (wnext >= wend && more) {
                 uint32_t base = 0;
@@ -550,7 +551,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                 const uint32_t nw = (uint32_t)__popcll(want);
                 wnext = wnext + nw < wend ? wnext + nw : wend;
             }
-            if (!__any(active) && !more && wnext >= wend) { if (SPH) dw.pad(lane); break; }
+            if (!__any(active) && !more && wnext >= wend) { if (MIXED) dw.pad(lane); break; }
         }
         if (active) {
             // ---- one node step (the pop of an exhausted group is merged into it)
@@ -624,7 +625,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                     const uint32_t cnt = meta >> 5, off = meta & 31u;
                     for (uint32_t j = 0; j < cnt && !(ANY && (found || PM_SURE)); ++j) {
                         if (COUNT) ctr->prims++;
-                        if (ptype == PM_PRIM_SPHERE) {
+                        if (MIXED && ptype == PM_PRIM_SPHERE) {
                             const uint4* r = prims + pbase + (off + j) * PM_UNITS_SPHERE;
                             float m[12];
                             const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
@@ -633,7 +634,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                             m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
                             const float radius = __uint_as_float(r3.x), zmin = __uint_as_float(r3.y), zmax = __uint_as_float(r3.z),
                                         phimax = __uint_as_float(r3.w);
-                            if (SPH && !exact_mode) {
+                            if (!exact_mode) {
                                 if (!sphere_prefilter(ray.o, ray.d, R, D, m, radius, __uint_as_float(r4.z), __uint_as_float(r4.w), tcull))
                                     continue;
                                 const uint32_t unit = pbase + (off + j) * PM_UNITS_SPHERE;
@@ -672,7 +673,15 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                                     }
                                 }
                             }
-                            if (immediate) {    // patches; triangles when the queue is full or in the fallback walk
+                            if (!MIXED && immediate) {      // (triangles only) the queue is full, or the fallback walk
+                                if (COUNT) ctr->exact++;
+                                float t, u, v;
+                                if (intersect_tri_exact(ray.o, ray.d, tmax, p00, p10, p01, &t, &u, &v)) {
+                                    tmax = t; found = true; hit.prim_id = r2.y; hit.t = t; hit.u = u; hit.v = v;
+                                    if (exact_mode) tcull = fminf(tcull, t);
+                                }
+                            }
+                            if (MIXED && immediate) {    // patches; triangles when the queue is full or in the fallback walk
                                 f3 p11 = p01;
                                 uint32_t id = r2.y;
                                 if (!is_tri) {

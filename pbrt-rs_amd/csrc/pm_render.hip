@@ -99,7 +99,7 @@ __global__ __launch_bounds__(RB) void raygen_kernel(RenderConst rc, SceneArrays 
 }
 
 // ------------------------------------------------------------------------------------------ traversal
-template <bool COUNT, bool SPH>
+template <bool COUNT, bool MIXED>
 __global__ __launch_bounds__(TB) PM_TRAV_ATTR void closest_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
                                                      const uint32_t* __restrict__ count, uint32_t* __restrict__ work, uint32_t refill,
                                                      uint4* __restrict__ defer_list, unsigned long long* __restrict__ counters) {
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR void closest_kernel(SceneArrays sc
     auto commit = [&](uint32_t i, bool found, const HitRec& h) {
         pa.hit[queue[i]] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
     };
-    trace_persistent<false, COUNT, SPH>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB,
+    trace_persistent<false, COUNT, MIXED>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB,
                                    defer_list, work + PM_WORK_SLOTS, &tc, fetch, commit);
     if (COUNT) {
         atomicAdd(&counters[1], (unsigned long long)tc.nodes); atomicAdd(&counters[2], (unsigned long long)tc.prims);
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR void closest_kernel(SceneArrays sc
     }
     if (tc.overflow) atomicAdd(&counters[3], 1ull);
 }
-template <bool COUNT, bool SPH>
+template <bool COUNT, bool MIXED>
 __global__ __launch_bounds__(TB) PM_TRAV_ATTR void shadow_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ count,
                                                     uint32_t* __restrict__ work, uint32_t refill, uint4* __restrict__ defer_list,
                                                     unsigned long long* __restrict__ counters) {
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR void shadow_kernel(SceneArrays sc,
             pa.L[slot] = L;
         }
     };
-    trace_persistent<true, COUNT, SPH>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB,
+    trace_persistent<true, COUNT, MIXED>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB,
                                   defer_list, work + PM_WORK_SLOTS, &tc, fetch, commit);
     if (COUNT) {
         atomicAdd(&counters[4], (unsigned long long)tc.nodes); atomicAdd(&counters[5], (unsigned long long)tc.prims);
@@ -898,6 +898,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     if ((rcode = ensure_paths(c, r, max_paths, p->max_depth, random_walk))) return rcode;
     if ((rcode = ensure_defer(c, max_paths))) return rcode;
     const bool has_spheres = !c->scene.spheres.empty();
+    const bool mixed = has_spheres || !c->scene.patches.empty();      // tree-walk kernel variant
 
     RenderConst rc{};
     std::memcpy(rc.cfr, r->cam.camera_from_raster, 64); std::memcpy(rc.rfc, r->cam.render_from_camera, 48);
@@ -953,8 +954,8 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
                                           : (fpatch ? closest_flat_kernel<false, true> : closest_flat_kernel<false, false>);
                 hipLaunchKernelGGL(kernel, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, qin, cnt_in, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_slow, c->d_counters);
             } else {
-                auto kernel = c->counting ? (has_spheres ? closest_kernel<true, true> : closest_kernel<true, false>)
-                                          : (has_spheres ? closest_kernel<false, true> : closest_kernel<false, false>);
+                auto kernel = c->counting ? (mixed ? closest_kernel<true, true> : closest_kernel<true, false>)
+                                          : (mixed ? closest_kernel<false, true> : closest_kernel<false, false>);
                 hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_work + wslot, c->refill, c->d_defer, c->d_counters);
             }
             if (has_spheres || flat) {     // second pass: dense exact tests of what was deferred (timed with the closest-hit class)
@@ -972,8 +973,8 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
                                               : (fpatch ? shadow_flat_kernel<false, true> : shadow_flat_kernel<false, false>);
                     hipLaunchKernelGGL(kernel, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, cnt_sh, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_slow, c->d_counters);
                 } else {
-                    auto kernel = c->counting ? (has_spheres ? shadow_kernel<true, true> : shadow_kernel<true, false>)
-                                              : (has_spheres ? shadow_kernel<false, true> : shadow_kernel<false, false>);
+                    auto kernel = c->counting ? (mixed ? shadow_kernel<true, true> : shadow_kernel<true, false>)
+                                              : (mixed ? shadow_kernel<false, true> : shadow_kernel<false, false>);
                     hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_work + wslot, c->refill, c->d_defer, c->d_counters);
                 }
                 if (has_spheres || flat) {
