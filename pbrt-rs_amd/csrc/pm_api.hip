@@ -309,7 +309,7 @@ extern "C" int pm_build_accel(pm_ctx* c, int split_method, int max_prims_in_node
     c->accel_valid = true;
     // refill threshold of the persistent traversal waves: walks through a tiny tree all have about the same (short)
     // length, so refilling early only multiplies the exact-test rounds; deep trees have long-tailed walks.
-    c->refill = c->accel.nodes.size() <= 64 ? 64u : 32u;     // measured: scripts/refill_sweep.sh, profiles/r01/refill_sweep.log
+    c->refill = c->accel.nodes.size() <= 64 ? 64u : 24u;     // measured: scripts/refill_sweep.sh, profiles/r01/refill_sweep*.log
     if (const char* e = std::getenv("PBRT_MI355_REFILL")) { int v = std::atoi(e); if (v >= 1 && v <= 64) c->refill = (uint32_t)v; }
     if (info) {
         info->n_prims = c->scene.next_prim_id;
