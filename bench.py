@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="path workload: skip the C3 closest-hit figure")
     ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="rays in the bounded CPU-baseline sample (trace; about 20 core-seconds)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time bound (path)")
+    ap.add_argument("--max-leaf", type=int, default=4, help="max_prims_in_node of BVHAggregate::new (wide leaves hold <= 4)")
     ap.add_argument("--split", default="sah", choices=["sah", "hlbvh"],
                     help="BVH build: binned SAH on the host (default) or the linear BVH built on the device (triangle scenes)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
@@ -126,7 +127,7 @@ def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, wan
     res = args.res or 4096
     pos, idx = pm.scenes.blob_mesh(args.blobs, 1024, seed=1)
     split = pm._capi.PM_SPLIT_HLBVH if args.split == "hlbvh" else pm._capi.PM_SPLIT_SAH
-    agg = pm.GpuAggregate([pm.TriangleMesh(pos, idx)], device_id=local_rank, split_method=split)
+    agg = pm.GpuAggregate([pm.TriangleMesh(pos, idx)], max_prims_in_node=args.max_leaf, device_id=local_rank, split_method=split)
     rays = pm.scenes.primary_rays(res, res, eye=(0.02 * rank, 0.0, -4.0))
     n_rays = len(rays)
     d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
@@ -274,7 +275,8 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup):
         name = f"C2 Cornell box path tracing: {rw}x{rh} @ {spp} spp per GPU"
     spp_total = spp * world
     integ = pm.WavefrontIntegrator(args.max_depth, True, True, sd, spp_total, seed=0, device_id=local_rank,
-                                   split_method=pm._capi.PM_SPLIT_HLBVH if args.split == "hlbvh" else pm._capi.PM_SPLIT_SAH)
+                                   split_method=pm._capi.PM_SPLIT_HLBVH if args.split == "hlbvh" else pm._capi.PM_SPLIT_SAH,
+                                   max_prims_in_node=args.max_leaf)
     s0, s1 = pm.distributed.shard_samples(spp_total, rank, world)
     film = torch.empty((rh, rw, 4), dtype=torch.float64, device="cuda")
 

@@ -301,7 +301,11 @@ int build_accel(const HostScene& sc, int max_leaf, Accel& acc, std::string& err)
         TypeTree& t = trees.back();
         t.type = type; t.boxes.resize(n); t.order.resize(n); t.l2g.resize(n);
         for (size_t i = 0; i < n; ++i) { t.boxes[i] = box_fn(i); t.order[i] = (uint32_t)i; t.l2g[i] = (uint32_t)i; }
-        BinBuilder bb(t.boxes, t.order, max_leaf);
+        // Triangles always get single-primitive leaves: in a 64-lane wave every extra primitive of a leaf is an extra
+        // pre-filter trip for all lanes, which costs more than the node it saves (measured, profiles/r01/leaf_sweep.log:
+        // leaves <= 4 / <= 2 / 1 -> 2218 / 2233 / 2339 Mrays/s on C3, 214 / 221 / 252 Msamples/s on the C4-shaped scene).
+        // max_prims_in_node stays the upper bound for spheres and patches, whose tests are not pre-filtered in the walk.
+        BinBuilder bb(t.boxes, t.order, type == PM_PRIM_TRI ? 1 : max_leaf);
         t.bn.reserve(2 * n);
         t.root = bb.build(t.bn, 0, (uint32_t)n, 0);
     };
