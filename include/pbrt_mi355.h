@@ -103,7 +103,9 @@ int pm_add_triangle_mesh(pm_ctx* ctx, const float* pos_xyz, uint32_t n_vert, con
                          uint32_t* first_prim_id);
 int pm_clear_geometry(pm_ctx* ctx);
 
-/* BVHAggregate::new (primitives/aggregates.rs:25-47): builds the wide BVH on the host and uploads it. */
+/* BVHAggregate::new (primitives/aggregates.rs:25-47): builds the wide BVH (on the host, or on the device for
+ * PM_SPLIT_HLBVH) and uploads it.  max_prims_in_node is an upper bound, as in the reference (whose SAH may stop earlier):
+ * wide leaves hold at most 4 primitives, and triangle leaves always hold one (measured faster on 64-lane waves). */
 int pm_build_accel(pm_ctx* ctx, int split_method, int max_prims_in_node, PmAccelInfo* info_or_null);
 
 /* ---- batched Primitive::intersect / intersect_p --------------------------------------------- */

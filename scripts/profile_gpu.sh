@@ -13,7 +13,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_path -o path --
 step stats-trace
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_trace -o trace --output-format csv -- python3 bench.py --workload trace --steps 5 --warmup 1 --no-cpu-baseline > $OUT/stats_trace.log 2>&1 || exit 1
 for W in path trace; do
-  if [ $W = path ]; then ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-secondary"; else ARGS="--workload trace --steps 1 --warmup 0 --no-cpu-baseline"; fi
+  if [ $W = path ]; then ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-secondary"; else ARGS="--workload trace --steps 1 --warmup 0 --no-cpu-baseline --no-secondary"; fi   # primary rays only: one kernel, one ray set
   step pmc-fetch-$W
   timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum -d $OUT/pmc_fetch_$W -o f --output-format csv -- python3 bench.py $ARGS > $OUT/pmc_fetch_$W.log 2>&1 || exit 1
   step pmc-write-$W
