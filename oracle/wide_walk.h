@@ -335,7 +335,7 @@ struct WideWalker {
                     float f = rmin(rmin(tf[0], tf[1]), rmin(tf[2], tcull));
                     if (n <= f) hits |= 1u << s;
                 }
-                hits &= (uint32_t)nd.imask | nonzero_meta_mask(nd);
+                // (unused child slots hold an inverted box; should one pass the slab test it is a leaf of zero primitives)
                 uint32_t lm = perm8(hits & ~(uint32_t)nd.imask, oct);
                 uint32_t type = nd.prim_base >> 30, pbase = nd.prim_base & 0x3FFFFFFFu;
                 uint32_t units = type == 2 ? 3 : (type == 1 ? 4 : 5);

@@ -445,6 +445,12 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                           TravCounters* ctr, FetchFn fetch, CommitFn commit) {
     const float widen = 1.0f + 2.0f * gamma_n(3);
     const uint32_t lane = threadIdx.x & 63u;
+    // perm8 for every (octant, mask) as a 2 KB table in LDS: one ds_read_u8 instead of ~15 VALU instructions, twice per node
+    // step (the walk is VALU-issue bound)
+    __shared__ uint8_t ptab[8 * 256];
+    for (uint32_t i = threadIdx.x; i < 8u * 256u; i += blockDim.x) ptab[i] = (uint8_t)perm8(i & 0xFFu, i >> 8);
+    __syncthreads();
+#define PM_PERM8(m) ((uint32_t)ptab[(oct << 8) | (m)])
     bool active = false;       // this lane is walking a ray
     bool finished = false;     // its walk has ended; exact tests + commit pending
     bool more = true;          // wave-uniform: the pool may still hold items
@@ -583,7 +589,6 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
                 if (COUNT) ctr->nodes++;
                 const uint32_t imask = n0.w >> 24;
-                const uint32_t vmask = imask | nonzero_bytes4(n1.z) | (nonzero_bytes4(n1.w) << 4);
                 // ---- pre-scaled slab test: t = q * (scale/d) + (origin - o)/d, margins folded into the addends
                 const float sxi = __uint_as_float((n0.w & 0xFFu) << 23) * inv.x;
                 const float syi = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23) * inv.y;
@@ -611,9 +616,10 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                                            fminf(__fmaf_rn(ubyte(qfz[w], kk), szf, afz), tcull));
                     if (tn <= tf) hits |= 1u << s;
                 }
-                hits &= vmask;
+                // (unused child slots hold an inverted box, which the slab test rejects; should one pass on a node that is flat
+                // along the only axis a ray constrains, it is a leaf of zero primitives)
                 // ---- leaves of this node, front to back by octant order
-                uint32_t lm = perm8(hits & ~imask, oct);
+                uint32_t lm = PM_PERM8(hits & ~imask);
                 const uint32_t ptype = n1.y >> 30;
                 const uint32_t pbase = n1.y & 0x3FFFFFFFu;
                 const uint32_t metaw[2] = {n1.z, n1.w};
@@ -700,12 +706,13 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                     }
                 }
                 // ---- descend into the interior children that were hit
-                cur = make_uint2(n1.x, (imask << 8) | perm8(hits & imask, oct));
+                cur = make_uint2(n1.x, (imask << 8) | PM_PERM8(hits & imask));
             }
         }
     }
 }
 #undef PM_SURE
+#undef PM_PERM8
 
 // ---- scenes of at most PM_FLAT_MAX_PRIMS primitives: no tree.  Every wave takes 64 consecutive work items and sweeps the
 // whole flat table (pm_layout.h) in lock step: the records are wave-uniform (scalar loads), nothing diverges but the
