@@ -16,13 +16,15 @@ struct RenderState;   // pm_render.hip
 #define TRACE_BLOCK 128
 #define PM_WORK_SLOTS 64
 #ifndef PM_BLOCKS_PER_CU
-#define PM_BLOCKS_PER_CU 8      // persistent traversal grids: 8 blocks x 2 waves per CU = 4 waves per SIMD
+#define PM_BLOCKS_PER_CU 13     // persistent traversal grids: 13 blocks x 2 waves per CU = 6.5 waves per SIMD, what the
+                                // blocks' 12 KB of LDS lets a CU hold (pm_layout.h PM_LDS_STACK)
 #endif
 #ifndef PM_FLAT_BLOCKS_PER_CU
 #define PM_FLAT_BLOCKS_PER_CU 16    // flat-sweep grids (grid-stride over 64-item groups): small kernels, high occupancy
 #endif
 #ifndef PM_FLAT_WAVES_PER_EU
-#define PM_FLAT_WAVES_PER_EU 5      // measured (scripts/ab_flat.sh): 5 waves/SIMD beat the compiler's choice (4); 6 spills
+#define PM_FLAT_WAVES_PER_EU 8      // measured (scripts/ab_path.sh): with the SLP vectoriser off the sweep fits 64 VGPRs, and
+                                    // 8 waves/SIMD (= the 16 x 2 waves per CU of the grid) beat 5 by 9 %
 #endif
 #if PM_FLAT_WAVES_PER_EU > 0
 #define PM_FLAT_ATTR __attribute__((amdgpu_waves_per_eu(PM_FLAT_WAVES_PER_EU, PM_FLAT_WAVES_PER_EU)))
@@ -30,8 +32,8 @@ struct RenderState;   // pm_render.hip
 #define PM_FLAT_ATTR
 #endif
 #ifndef PM_WAVES_PER_EU
-#define PM_WAVES_PER_EU 4           // tree-walk kernels: capping VGPRs for 4 waves/SIMD (the compiler picks 3) measured +8 %
-#endif                              // on the C4-shaped path workload, +10 % on incoherent C3 rays (scripts/ab_bvh.sh)
+#define PM_WAVES_PER_EU 8           // tree-walk kernels: VGPR budget of 8 waves/SIMD (64).  Measured with scripts/ab_bvh.sh at 4..8:
+#endif                              // each step down in registers was a step up in speed, also where LDS held occupancy at 4
 #if PM_WAVES_PER_EU > 0
 #define PM_TRAV_ATTR __attribute__((amdgpu_waves_per_eu(PM_WAVES_PER_EU, PM_WAVES_PER_EU)))
 #else
