@@ -32,13 +32,12 @@ struct RenderState;   // pm_render.hip
 #define PM_FLAT_ATTR
 #endif
 #ifndef PM_WAVES_PER_EU
-#define PM_WAVES_PER_EU 8           // tree-walk kernels: VGPR budget of 8 waves/SIMD (64).  Measured with scripts/ab_bvh.sh at 4..8:
-#endif                              // each step down in registers was a step up in speed, also where LDS held occupancy at 4
-#if PM_WAVES_PER_EU > 0
-#define PM_TRAV_ATTR __attribute__((amdgpu_waves_per_eu(PM_WAVES_PER_EU, PM_WAVES_PER_EU)))
-#else
-#define PM_TRAV_ATTR
+#define PM_WAVES_PER_EU 5           // tree-walk kernels, closest hit: VGPR budget of 5 waves/SIMD (96)
 #endif
+#ifndef PM_ANY_WAVES_PER_EU
+#define PM_ANY_WAVES_PER_EU 5       // tree-walk kernels, any hit (6 = 80 VGPRs measured slower, 7 spills into the node step)
+#endif
+#define PM_TRAV_ATTR(any) __attribute__((amdgpu_waves_per_eu((any) ? PM_ANY_WAVES_PER_EU : PM_WAVES_PER_EU, (any) ? PM_ANY_WAVES_PER_EU : PM_WAVES_PER_EU)))
 
 struct pm_ctx {
     int device = 0;
