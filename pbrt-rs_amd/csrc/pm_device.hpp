@@ -483,7 +483,11 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
 
     // Work items are reserved from the global counter in chunks (one atomic per chunk, not per refill) sized so that every
     // wave of the grid gets several chunks: [wnext, wend) is this wave's current reservation (wave-uniform).
-    uint32_t chunk = n_items / (gridDim.x * (blockDim.x >> 6) * 4u);
+    // 16 chunks per wave measured best (scripts/ab_bvh.sh: +9 % on C3 over 4; 32 is past the optimum).  All waves of the
+    // chip draw from ONE counter on purpose: they then work inside one narrow window of the items, which the XCDs' L2s and the
+    // Infinity Cache share.  Giving each XCD group (blockIdx % 8) its own eighth of the items was measured 5 % (C3) to 15 %
+    // (C4-shaped path) slower.
+    uint32_t chunk = n_items / (gridDim.x * (blockDim.x >> 6) * 16u);
     chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : (chunk & ~63u));
     uint32_t wnext = 0, wend = 0;
     DeferWriter dw; dw.list = defer_list; dw.count = defer_count; dw.next = 0u; dw.end = 0u;
