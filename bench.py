@@ -178,7 +178,10 @@ def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, wan
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(r"^trace(_flat)?_kernel<false, false", "trace")[0],
                      "traffic_source": pmc_traffic(r"^trace(_flat)?_kernel<false, false", "trace")[1],
                      "kernel": "trace_kernel<false,false>", "kernel_ms": k_ms,
-                     "bytes_per_ray": bytes_per_ray, "nodes_per_ray": n_node, "prims_per_ray": n_prim},
+                     "bytes_per_ray": bytes_per_ray, "nodes_per_ray": n_node, "prims_per_ray": n_prim,
+                     "note": "achieved = DEMAND bytes (every node / record fetch of the walk counted as a miss, SURVEY 8d) per "
+                             "second; this tree fits the L2s + Infinity Cache, so the HBM side moves far less (traffic = PMC "
+                             "bytes per launch) and the kernel is bound by instruction issue, not by HBM"},
     }
     if not args.no_secondary:
         # SURVEY.md 8(d) C3's other two ray sets, each with its own counters and event-timed launches (not `value`)

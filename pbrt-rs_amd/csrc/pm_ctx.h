@@ -16,8 +16,8 @@ struct RenderState;   // pm_render.hip
 #define TRACE_BLOCK 128
 #define PM_WORK_SLOTS 64
 #ifndef PM_BLOCKS_PER_CU
-#define PM_BLOCKS_PER_CU 13     // persistent traversal grids: 13 blocks x 2 waves per CU = 6.5 waves per SIMD, what the
-                                // blocks' 12 KB of LDS lets a CU hold (pm_layout.h PM_LDS_STACK)
+#define PM_BLOCKS_PER_CU 10     // persistent traversal grids: 10 blocks x 2 waves per CU = 5 waves per SIMD, all resident
+                                // (96 VGPRs, 14 KB of LDS per block: pm_layout.h PM_LDS_STACK)
 #endif
 #ifndef PM_FLAT_BLOCKS_PER_CU
 #define PM_FLAT_BLOCKS_PER_CU 16    // flat-sweep grids (grid-stride over 64-item groups): small kernels, high occupancy

@@ -65,8 +65,8 @@ struct PmFlatScene { const PmFlatTri* tris; const uint32_t* units; uint32_t n_sp
 
 #define PM_MAX_LEAF 4
 #ifndef PM_LDS_STACK
-#define PM_LDS_STACK 6       // per-lane entries kept in LDS (6 KB per 128-lane block: with the candidate queue and the
-                             // permutation table a block takes 12 KB, so 13 blocks = 6.5 waves per SIMD fit the CU's 160 KB;
-                             // 12 entries held the walk to 4 waves per SIMD. measured: C4-shaped path +7 %, shadow rays +7 %)
+#define PM_LDS_STACK 8       // per-lane entries kept in LDS (8 KB per 128-lane block: with the candidate queue and the
+                             // permutation table a block takes 14 KB, so the 10 blocks = 5 waves per SIMD that the kernels'
+                             // registers allow fit the CU's 160 KB; 12 entries held the walk to 4 waves per SIMD)
 #endif
 #define PM_SPILL_STACK (48 - PM_LDS_STACK)    // per-lane overflow entries (private memory)
