@@ -890,7 +890,12 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     if (W == 0 || H == 0 || s0 == s1) return PM_OK;
     const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
     const size_t npix_pad = (size_t)tiles_x * tiles_y * 64;
-    const size_t target = (size_t)1 << 23;
+    // paths per pass: 2^26 (13 GB of path state + 1 GB of deferred list - sized for a 288 GB device).  Measured
+    // (scripts/pass_sweep.sh): every doubling from 2^20 helped the persistent traversal kernels (fewer, longer launches: less
+    // tail, fewer small deep-bounce queues) up to 2^25..2^26: C2 +11 %, C4-shaped path +10 % over 2^23.
+    // PBRT_MI355_PASS_PATHS overrides (tuning aid; the tests use it to force several passes).
+    size_t target = (size_t)1 << 26;
+    if (const char* e = std::getenv("PBRT_MI355_PASS_PATHS")) { long long v = std::atoll(e); if (v >= 64 && v <= (1ll << 30)) target = (size_t)v; }
     int s_per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)(s1 - s0), target / npix_pad));
     const size_t max_paths = npix_pad * (size_t)s_per_pass;
     if (max_paths > 0x7FFFFFFFull) return fail(c, PM_ERR_INVALID, "pm_render: window too large for one pass");

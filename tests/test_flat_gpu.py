@@ -69,3 +69,25 @@ def test_cornell_film_flat_equals_tree(pm, monkeypatch):
     assert sa["closest_rays"] == sb["closest_rays"] and sa["shadow_rays"] == sb["shadow_rays"]
     differing = (fa != fb).any(axis=-1).mean()
     assert differing < 1e-3, differing          # exact-t ties along shared edges may pick the other triangle
+
+
+@pytest.mark.gpu
+def test_film_independent_of_pass_size(pm, monkeypatch):
+    """pm_render cuts the sample range into passes of at most PBRT_MI355_PASS_PATHS paths; the film (f64 sums in
+    sample-index order, film.rs add_sample) and the ray counts must not depend on where the cuts fall."""
+    sd = pm.scenes.cornell_scene((64, 64))
+    films = []
+    for paths in (None, "4096", "12288"):       # one pass; one sample per pass; three samples per pass (8 = 3 + 3 + 2)
+        if paths is None:
+            monkeypatch.delenv("PBRT_MI355_PASS_PATHS", raising=False)
+        else:
+            monkeypatch.setenv("PBRT_MI355_PASS_PATHS", paths)
+        integ = pm.WavefrontIntegrator(5, True, True, sd, 8, seed=1)
+        integ.clear()
+        st = integ.render()
+        films.append((integ.film().copy(), st))
+        del integ
+    assert [f[1]["passes"] for f in films] == [1, 8, 3]
+    for f, st in films[1:]:
+        assert st["closest_rays"] == films[0][1]["closest_rays"] and st["shadow_rays"] == films[0][1]["shadow_rays"]
+        assert np.array_equal(f, films[0][0])
