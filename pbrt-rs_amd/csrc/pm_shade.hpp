@@ -17,6 +17,36 @@ namespace pmd {
 
 PMD float cr_sin(float x) { return (float)sin((double)x); }
 PMD float cr_cos(float x) { return (float)cos((double)x); }
+// sin and cos of one angle: one argument reduction instead of two
+PMD void cr_sincos(float x, float* sn, float* cs) { double s, c; sincos((double)x, &s, &c); *sn = (float)s; *cs = (float)c; }
+// ... for the concentric disk mapping, whose angle lies in [-pi/4, 3pi/4]: no argument reduction at all.  Taylor series in
+// double (|t| <= pi/4: the first neglected terms are 8e-20 and 2e-18), so the result is the correctly rounded float like
+// (float)sin((double)x) except where the exact value lies within ~2^-52 (relative) of a rounding boundary.
+PMD void cr_sincos_quarter(float x, float* sn, float* cs) {
+    const bool upper = x > 0.78539816339744830962f;              // then t = x - pi/2 in [-pi/4, pi/4]: sin x = cos t, cos x = -sin t
+    const double t = upper ? (double)x - 1.57079632679489661923 : (double)x;
+    const double t2 = t * t;
+    double ps = 2.8114572543455206e-15;                          // 1/17!
+    ps = fma(ps, t2, -7.6471637318198164e-13);                   // -1/15!
+    ps = fma(ps, t2, 1.6059043836821613e-10);                    // 1/13!
+    ps = fma(ps, t2, -2.5052108385441720e-08);                   // -1/11!
+    ps = fma(ps, t2, 2.7557319223985893e-06);                    // 1/9!
+    ps = fma(ps, t2, -1.9841269841269841e-04);                   // -1/7!
+    ps = fma(ps, t2, 8.3333333333333332e-03);                    // 1/5!
+    ps = fma(ps, t2, -1.6666666666666666e-01);                   // -1/3!
+    const double s = fma(ps * t2, t, t);
+    double pc = 4.7794773323873853e-14;                          // 1/16!
+    pc = fma(pc, t2, -1.1470745597729725e-11);                   // -1/14!
+    pc = fma(pc, t2, 2.0876756987868100e-09);                    // 1/12!
+    pc = fma(pc, t2, -2.7557319223985888e-07);                   // -1/10!
+    pc = fma(pc, t2, 2.4801587301587302e-05);                    // 1/8!
+    pc = fma(pc, t2, -1.3888888888888889e-03);                   // -1/6!
+    pc = fma(pc, t2, 4.1666666666666664e-02);                    // 1/4!
+    pc = fma(pc, t2, -0.5);
+    const double c = fma(pc, t2, 1.0);
+    *sn = (float)(upper ? c : s);
+    *cs = (float)(upper ? -s : c);
+}
 PMD float cr_atanh(float x) { return (float)atanh((double)x); }
 PMD float cr_cosh(float x) { return (float)cosh((double)x); }
 PMD float cr_exp(float x) { return (float)exp((double)x); }
@@ -115,13 +145,15 @@ PMD f3 sample_uniform_sphere(f2 u) {
     const float z = 1.0f - 2.0f * u.x;
     const float r = safe_sqrtf(1.0f - z * z);
     const float phi = 2.0f * PM_PI * u.y;
-    return mk3(r * cr_cos(phi), r * cr_sin(phi), z);
+    float sp, cp; cr_sincos(phi, &sp, &cp);
+    return mk3(r * cp, r * sp, z);
 }
 PMD f3 sample_uniform_hemisphere(f2 u) {
     const float z = u.x;
     const float r = safe_sqrtf(1.0f - z * z);
     const float phi = 2.0f * PM_PI * u.y;
-    return mk3(r * cr_cos(phi), r * cr_sin(phi), z);
+    float sp, cp; cr_sincos(phi, &sp, &cp);
+    return mk3(r * cp, r * sp, z);
 }
 PMD f2 sample_disk_concentric(f2 u) {
     f2 o; o.x = 2.0f * u.x - 1.0f; o.y = 2.0f * u.y - 1.0f;
@@ -130,13 +162,15 @@ PMD f2 sample_disk_concentric(f2 u) {
     float r, th;
     if (fabsf(o.x) > fabsf(o.y)) { r = o.x; th = PM_PI_4 * (o.y / o.x); }
     else { r = o.y; th = PM_PI_2 - PM_PI_4 * (o.x / o.y); }
-    f2 p; p.x = cr_cos(th) * r; p.y = cr_sin(th) * r;
+    float st, ct; cr_sincos_quarter(th, &st, &ct);
+    f2 p; p.x = ct * r; p.y = st * r;
     return p;
 }
 PMD f2 sample_disk_polar(f2 u) {
     const float r = sqrtf(u.x);
     const float th = 2.0f * PM_PI * u.y;
-    f2 p; p.x = r * cr_cos(th); p.y = r * cr_sin(th);
+    float st, ct; cr_sincos(th, &st, &ct);
+    f2 p; p.x = r * ct; p.y = r * st;
     return p;
 }
 PMD f3 sample_cosine_hemisphere(f2 u) {
