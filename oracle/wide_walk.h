@@ -151,7 +151,6 @@ struct WideWalker {
         }
         return true;
     }
-    static uint32_t nonzero_meta_mask(const WNode& nd) { uint32_t m = 0; for (int s = 0; s < 8; ++s) if (nd.meta[s]) m |= 1u << s; return m; }
 
     // ---- flat sweep (pm_device.hpp trace_flat) for scenes of at most PM_FLAT_MAX_PRIMS primitives.  The table is derived
     // from the exported buffers exactly as pm_build.cpp build_flat_table derives it: node index, slot, record order.

@@ -214,11 +214,6 @@ PMD uint32_t perm8(uint32_t m, uint32_t oct) {   // bit k of result = bit (k ^ o
     return m;
 }
 PMD float ubyte(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }
-// bit k of the result = (byte k of w != 0), k = 0..3
-PMD uint32_t nonzero_bytes4(uint32_t w) {
-    const uint32_t t = ((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w;          // bit 7 of each byte = byte != 0
-    return ((((t >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
-}
 
 struct TravCounters { uint32_t nodes, prims, exact, overflow, fallback; };
 
