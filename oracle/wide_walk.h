@@ -244,7 +244,10 @@ struct WideWalker {
         }
         if (!slow) {
             const float tconf = next_float_down(cull.cn / cull.cd);
-            for (const Cand& cu : cand) {
+            // any hit: last candidate first (a certain hit ends the sweep, so it is the last one queued and the round is over
+            // after one test; the candidates before it are mostly the triangle the shadow ray starts on)
+            for (size_t ci = 0; ci < cand.size(); ++ci) {
+                const Cand& cu = cand[any_hit ? cand.size() - 1 - ci : ci];
                 if (cu.ln * cull.cd > cull.cn * cu.ld) continue;        // behind another certain hit (filtered before the round)
                 if (any_hit && found) break;
                 (void)test_now(2, cu.unit);
@@ -374,7 +377,8 @@ struct WideWalker {
                 }
                 cur = Group{nd.child_base, nd.imask, perm8(hits & nd.imask, oct)};
             }
-            for (const auto& cu : cand) {
+            for (size_t ci = 0; ci < cand.size(); ++ci) {       // any hit: last candidate first (see walk_flat)
+                const auto& cu = cand[any_hit ? cand.size() - 1 - ci : ci];
                 if (any_hit && found) break;
                 if (cu.second > tcull) continue;        // behind another certain hit
                 if (ctr) ctr->exact_tests++;

@@ -493,9 +493,13 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
             // ---- lanes whose walk has ended: exact tests of the queued triangles, in the order they were met
             bool defer = false;
             if (finished) {
-                for (uint32_t qi = 0; qi < PM_CAND_MAX; ++qi) {
+                for (uint32_t qj = 0; qj < PM_CAND_MAX; ++qj) {
+                    if (qj >= qn || (ANY && found)) continue;
+                    // any hit: last candidate first - a certain hit ends the walk, so it is the last one queued, and the round
+                    // is over after one test (the candidates before it are mostly the triangle the shadow ray starts on)
+                    const uint32_t qi = ANY ? qn - 1u - qj : qj;
                     // a certain hit whose t bracket starts beyond the final tcull lies behind another certain hit
-                    if (qi >= qn || (ANY && found) || __uint_as_float(cand[(PM_CAND_MAX + qi) * stride]) > tcull) continue;
+                    if (__uint_as_float(cand[(PM_CAND_MAX + qi) * stride]) > tcull) continue;
                     const uint4* r = prims + cand[qi * stride];
                     const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
                     const f3 v0 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
@@ -852,9 +856,10 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
         // what the closest hit must not exceed if culling was right: the fraction as a float, rounded DOWN (one value
         // kept across the exact round instead of two)
         const float tconf = fdn(cull.cn / cull.cd);
-        for (uint32_t qi = 0; qi < PM_FLAT_CAND_MAX; ++qi) {
-            if (!__any(live && !slow && qi < qn && !(ANY && found))) break;
-            if (live && !slow && qi < qn && !(ANY && found)) {
+        for (uint32_t qj = 0; qj < PM_FLAT_CAND_MAX; ++qj) {
+            if (!__any(live && !slow && qj < qn && !(ANY && found))) break;
+            if (live && !slow && qj < qn && !(ANY && found)) {
+                const uint32_t qi = ANY ? qn - 1u - qj : qj;       // any hit: last candidate (the certain hit) first
                 const uint4* r = prims + cand[qi * stride];
                 const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
                 const f3 v0 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
