@@ -896,6 +896,14 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     // PBRT_MI355_PASS_PATHS overrides (tuning aid; the tests use it to force several passes).
     size_t target = (size_t)1 << 26;
     if (const char* e = std::getenv("PBRT_MI355_PASS_PATHS")) { long long v = std::atoll(e); if (v >= 64 && v <= (1ll << 30)) target = (size_t)v; }
+    {   // ... but never more than half of the memory that is free on the device now (another process may share it)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t held = r->pa_cap * (size_t)(10 * 16 + 16 + 8 + 12);         // what ensure_paths would free first
+            const size_t per_path = 10 * 16 + 16 + 8 + 12 + 16 + 4 + (p->integrator == PM_INTEGRATOR_RANDOM_WALK ? (size_t)std::max(1, p->max_depth) * 16 : 0);
+            target = std::min(target, std::max<size_t>((size_t)1 << 16, (free_b + held) / 2 / per_path));
+        }
+    }
     int s_per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)(s1 - s0), target / npix_pad));
     const size_t max_paths = npix_pad * (size_t)s_per_pass;
     if (max_paths > 0x7FFFFFFFull) return fail(c, PM_ERR_INVALID, "pm_render: window too large for one pass");
