@@ -5,6 +5,8 @@ relative.  The leaf tests are op-for-op restatements, so these tests demand MORE
 for patches/triangles; for spheres ids and t bit-identical and (u,v) within 1e-5 (acos/atan2 come from
 different libms: glibc vs ROCm OCML).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -257,3 +259,34 @@ def test_device_pointers_in_place(pm, ora):
     ref, _ = sc.intersect(rays)
     _compare_closest(gpu, ref)
     assert agg.last_kernel_ms() > 0.0
+
+
+@pytest.mark.parametrize("seed", list(range(100, 100 + int(os.environ.get("PBRT_MI355_FUZZ_SEEDS", "4")))))
+def test_triangle_soups_more_seeds(pm, ora, seed):
+    """Triangle soups of several sizes (tree walk and flat sweep), closest and any hit: hits against the reference
+    traversal, hits and counters against the CPU mirror of the wide walk.  PBRT_MI355_FUZZ_SEEDS widens the sweep."""
+    blobs, per = [(8, 64), (64, 256), (256, 512), (3, 7)][seed % 4]
+    pos, idx = pm.scenes.blob_mesh(blobs, per, seed=seed)
+    agg, sc = _build_both(pm, ora, [("tri", pos, idx)])
+    rays = np.concatenate([pm.scenes.primary_rays(128, 128), pm.scenes.incoherent_rays(60_000, seed=seed + 1)])
+    ref, _ = sc.intersect(rays)
+    flat = agg.info.flat_prims != 0
+    agg.set_counting(True)
+    agg.reset_counters()
+    gpu = agg.intersect(rays)
+    c = agg.counters()
+    _compare_closest(gpu, ref)
+    cpu, cw = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays, flat=flat)
+    assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32))
+    for k in ("nodes_visited", "prims_tested", "exact_tests", "fallback_walks"):
+        assert c[k] == cw[k], (k, c, cw)
+    agg.reset_counters()
+    sh = pm.scenes.shadow_rays(rays, gpu)
+    ref_a, _ = sc.intersect_p(sh)
+    ga = agg.intersect_p(sh)
+    ca, cwa = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), sh, any_hit=True, flat=flat)
+    c2 = agg.counters()
+    assert np.array_equal(ga, ref_a) and np.array_equal(ga, ca)
+    for k in ("nodes_visited", "prims_tested", "exact_tests", "fallback_walks"):
+        assert c2[k] == cwa[k], (k, c2, cwa)
+    agg.set_counting(False)
