@@ -204,7 +204,10 @@ int pm_set_prim_materials(pm_ctx* ctx, const uint32_t* material_id_per_prim, uin
 int pm_set_lights(pm_ctx* ctx, const PmLight* lights, uint32_t n);
 int pm_set_camera(pm_ctx* ctx, const PmCamera* cam);
 int pm_set_film(pm_ctx* ctx, const PmFilm* film);           /* (re)allocates and clears the film */
-/* Integrate::render() restricted to a pixel/sample window; accumulates into the film in sample-index order */
+/* Integrate::render() restricted to a pixel/sample window; accumulates into the film in sample-index order.
+ * The window is rendered in passes of at most 2^26 paths (about 200 bytes of device memory per path, allocated on first
+ * use and kept; never more than half of what is free on the device; PBRT_MI355_PASS_PATHS lowers it).  The film does not
+ * depend on how the window is cut into passes. */
 int pm_render(pm_ctx* ctx, const PmRenderParams* params);
 int pm_film_clear(pm_ctx* ctx);
 /* RGBPixel{rgb_sum[3], weight_sum} as 4 doubles per pixel, row-major over pixel_bounds; host or device pointer */
