@@ -278,9 +278,12 @@ extern "C" int pm_build_accel(pm_ctx* c, int split_method, int max_prims_in_node
         else if (rc != PM_ERR_UNSUPPORTED) return fail(c, rc, "pm_build_accel: " + err);
     }
     // the reference's max_prims_in_node is u8 (main.rs passes 255); wide leaves hold at most PM_MAX_LEAF
-    if (!built_on_gpu && pm::build_accel(c->scene, max_prims_in_node, c->accel, err) != 0)
-        return fail(c, PM_ERR_INVALID, "pm_build_accel: " + err);
-    const size_t nb = c->accel.nodes.size() * sizeof(PmWideNode), pb = c->accel.prims.size();
+    if (!built_on_gpu) {
+        c->accel.dev_nodes = 0; c->accel.dev_prim_bytes = 0;
+        if (pm::build_accel(c->scene, max_prims_in_node, c->accel, err) != 0) return fail(c, PM_ERR_INVALID, "pm_build_accel: " + err);
+    }
+    const size_t n_nodes = built_on_gpu ? c->accel.dev_nodes : c->accel.nodes.size();
+    const size_t nb = n_nodes * sizeof(PmWideNode), pb = built_on_gpu ? c->accel.dev_prim_bytes : c->accel.prims.size();
     if (c->device >= 0 && !built_on_gpu) {
         if (c->d_nodes) { HIPCHK(c, hipFree(c->d_nodes)); c->d_nodes = nullptr; }
         if (c->d_prims) { HIPCHK(c, hipFree(c->d_prims)); c->d_prims = nullptr; }
@@ -309,11 +312,11 @@ extern "C" int pm_build_accel(pm_ctx* c, int split_method, int max_prims_in_node
     c->accel_valid = true;
     // refill threshold of the persistent traversal waves: walks through a tiny tree all have about the same (short)
     // length, so refilling early only multiplies the exact-test rounds; deep trees have long-tailed walks.
-    c->refill = c->accel.nodes.size() <= 64 ? 64u : 24u;     // measured: scripts/refill_sweep.sh, profiles/r01/refill_sweep*.log
+    c->refill = n_nodes <= 64 ? 64u : 24u;     // measured: scripts/refill_sweep.sh, profiles/r01/refill_sweep*.log
     if (const char* e = std::getenv("PBRT_MI355_REFILL")) { int v = std::atoi(e); if (v >= 1 && v <= 64) c->refill = (uint32_t)v; }
     if (info) {
         info->n_prims = c->scene.next_prim_id;
-        info->n_nodes = (uint32_t)c->accel.nodes.size();
+        info->n_nodes = (uint32_t)n_nodes;
         info->node_bytes = sizeof(PmWideNode);
         info->prim_record_bytes[0] = sizeof(PmSphereRecord);
         info->prim_record_bytes[1] = sizeof(PmPatchRecord);
@@ -429,16 +432,28 @@ extern "C" int pm_get_counters(pm_ctx* c, PmCounters* out) {
     return PM_OK;
 }
 extern "C" int pm_last_kernel_ms(pm_ctx* c, float* ms) { if (!c || !ms) return PM_ERR_INVALID; *ms = c->last_ms; return PM_OK; }
+// host copies of a tree that was built on the device, fetched when first asked for
+static int fetch_device_tree(pm_ctx* c) {
+    if (c->accel.dev_nodes == 0 || !c->accel.nodes.empty()) return PM_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->accel.nodes.resize(c->accel.dev_nodes);
+    c->accel.prims.resize(c->accel.dev_prim_bytes);
+    HIPCHK(c, hipMemcpy(c->accel.nodes.data(), c->d_nodes, c->accel.dev_nodes * sizeof(PmWideNode), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(c->accel.prims.data(), c->d_prims, c->accel.dev_prim_bytes, hipMemcpyDeviceToHost));
+    return PM_OK;
+}
 extern "C" int pm_get_node_buffer(pm_ctx* c, void* data, uint64_t cap, uint64_t* needed) {
     if (!c || !c->accel_valid) return fail(c, PM_ERR_NO_ACCEL, "no accel");
-    const uint64_t nb = c->accel.nodes.size() * sizeof(PmWideNode);
+    if (data) { const int rc = fetch_device_tree(c); if (rc) return rc; }
+    const uint64_t nb = (c->accel.dev_nodes ? c->accel.dev_nodes : c->accel.nodes.size()) * sizeof(PmWideNode);
     if (needed) *needed = nb;
     if (data) { if (cap < nb) return fail(c, PM_ERR_INVALID, "buffer too small"); std::memcpy(data, c->accel.nodes.data(), nb); }
     return PM_OK;
 }
 extern "C" int pm_get_prim_buffer(pm_ctx* c, void* data, uint64_t cap, uint64_t* needed) {
     if (!c || !c->accel_valid) return fail(c, PM_ERR_NO_ACCEL, "no accel");
-    const uint64_t nb = c->accel.prims.size();
+    if (data) { const int rc = fetch_device_tree(c); if (rc) return rc; }
+    const uint64_t nb = c->accel.dev_nodes ? c->accel.dev_prim_bytes : c->accel.prims.size();
     if (needed) *needed = nb;
     if (data) { if (cap < nb) return fail(c, PM_ERR_INVALID, "buffer too small"); std::memcpy(data, c->accel.prims.data(), nb); }
     return PM_OK;

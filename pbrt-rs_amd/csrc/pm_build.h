@@ -42,6 +42,9 @@ struct Accel {
     std::vector<uint8_t> prims;     // leaf records, 16-byte units
     Box bounds;
     double build_seconds = 0.0;
+    // a tree built on the device (pm_gpu_build.hip) stays there: nodes / prims above are empty and these say how large the
+    // device buffers are; pm_get_node_buffer / pm_get_prim_buffer fetch the host copies when somebody asks for them
+    size_t dev_nodes = 0, dev_prim_bytes = 0;
     // flat table of a scene small enough to be swept without a tree (pm_layout.h PmFlatTri; empty otherwise):
     // flat_n[0] sphere record units, then flat_n[1] patch record units (uint32 each), in flat_units; flat_n[2] triangles
     std::vector<PmFlatTri> flat_tris;

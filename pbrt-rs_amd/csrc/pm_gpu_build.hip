@@ -362,10 +362,11 @@ int pm_gpu_build_tris(pm_ctx* c, int max_leaf, std::string& err) {
     c->d_nodes = d_nodes;
     c->d_prims = reinterpret_cast<uint4*>(d_records);
     rec_guard.p = nullptr;
-    c->accel.nodes.resize(n_nodes);
-    c->accel.prims.resize(n * sizeof(PmTriRecord));
-    GBCHK(hipMemcpy(c->accel.nodes.data(), c->d_nodes, (size_t)n_nodes * sizeof(PmWideNode), hipMemcpyDeviceToHost));
-    GBCHK(hipMemcpy(c->accel.prims.data(), c->d_prims, n * sizeof(PmTriRecord), hipMemcpyDeviceToHost));
+    // no host copies here (1.3 GB over PCIe for the C4 scene): pm_get_node_buffer / pm_get_prim_buffer fetch them on demand
+    c->accel.nodes.clear(); c->accel.nodes.shrink_to_fit();
+    c->accel.prims.clear(); c->accel.prims.shrink_to_fit();
+    c->accel.dev_nodes = n_nodes;
+    c->accel.dev_prim_bytes = n * sizeof(PmTriRecord);
     for (int k = 0; k < 3; ++k) { c->accel.bounds.lo[k] = scene.lo[k]; c->accel.bounds.hi[k] = scene.hi[k]; }
     c->accel.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return PM_OK;
