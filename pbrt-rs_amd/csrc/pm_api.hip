@@ -7,7 +7,7 @@
 
 // ------------------------------------------------------------------------------------------ kernels
 template <bool ANY, bool COUNT, bool MIXED>
-__global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR(ANY) void trace_kernel(const PmWideNode* __restrict__ nodes,
+__global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR(ANY, MIXED) void trace_kernel(const PmWideNode* __restrict__ nodes,
                                                             const uint4* __restrict__ prims,
                                                             const PmRay* __restrict__ rays, uint32_t n,
                                                             PmHit* __restrict__ hits, uint8_t* __restrict__ occ,

@@ -37,7 +37,12 @@ struct RenderState;   // pm_render.hip
 #ifndef PM_ANY_WAVES_PER_EU
 #define PM_ANY_WAVES_PER_EU 5       // tree-walk kernels, any hit (6 = 80 VGPRs measured slower, 7 spills into the node step)
 #endif
-#define PM_TRAV_ATTR(any) __attribute__((amdgpu_waves_per_eu((any) ? PM_ANY_WAVES_PER_EU : PM_WAVES_PER_EU, (any) ? PM_ANY_WAVES_PER_EU : PM_WAVES_PER_EU)))
+#ifndef PM_MIXED_WAVES_PER_EU
+#define PM_MIXED_WAVES_PER_EU 4     // ... of scenes that hold spheres or patches as well: their walk carries more code, and 5
+                                    // waves (96 VGPRs) spill into it (scripts/mixed_probe.py: 4 beats 5 by 39 %, 3 by 3 %)
+#endif
+#define PM_TRAV_WAVES(any, mixed) ((mixed) ? PM_MIXED_WAVES_PER_EU : (any) ? PM_ANY_WAVES_PER_EU : PM_WAVES_PER_EU)
+#define PM_TRAV_ATTR(any, mixed) __attribute__((amdgpu_waves_per_eu(PM_TRAV_WAVES(any, mixed), PM_TRAV_WAVES(any, mixed))))
 
 struct pm_ctx {
     int device = 0;

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(RB) void raygen_kernel(RenderConst rc, SceneArrays 
 
 // ------------------------------------------------------------------------------------------ traversal
 template <bool COUNT, bool MIXED>
-__global__ __launch_bounds__(TB) PM_TRAV_ATTR(false) void closest_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(TB) PM_TRAV_ATTR(false, MIXED) void closest_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
                                                      const uint32_t* __restrict__ count, uint32_t* __restrict__ work, uint32_t refill,
                                                      uint4* __restrict__ defer_list, unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR(false) void closest_kernel(SceneAr
     if (tc.overflow) atomicAdd(&counters[3], 1ull);
 }
 template <bool COUNT, bool MIXED>
-__global__ __launch_bounds__(TB) PM_TRAV_ATTR(true) void shadow_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ count,
+__global__ __launch_bounds__(TB) PM_TRAV_ATTR(true, MIXED) void shadow_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ count,
                                                     uint32_t* __restrict__ work, uint32_t refill, uint4* __restrict__ defer_list,
                                                     unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
