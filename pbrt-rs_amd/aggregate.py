@@ -77,6 +77,13 @@ class GpuAggregate:
         if rc != _capi.PM_OK:
             raise PmError(f"pm_create(device {device_id}) failed with status {rc} (is a gfx950 GPU visible?)")
         self._h = h
+        self.rebuild(prims, max_prims_in_node, split_method, clear=False)
+
+    def rebuild(self, prims, max_prims_in_node=4, split_method=_capi.PM_SPLIT_SAH, clear=True):
+        """pm_clear_geometry + pm_add_* + pm_build_accel inside the same context (a new BVHAggregate::new over new
+        primitives; materials, lights, camera and film of the context stay)."""
+        if clear:
+            self._check(self._lib.pm_clear_geometry(self._h))
         self.first_prim_id = []
         first = C.c_uint32()
         for p in prims:

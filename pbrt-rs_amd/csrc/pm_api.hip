@@ -12,7 +12,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR(ANY, MIXED) void trace_ke
                                                             const PmRay* __restrict__ rays, uint32_t n,
                                                             PmHit* __restrict__ hits, uint8_t* __restrict__ occ,
                                                             uint32_t* __restrict__ work, uint32_t refill,
-                                                            uint4* __restrict__ defer_list,
+                                                            uint4* __restrict__ defer_list, uint32_t defer_cap,
                                                             unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TRACE_BLOCK];
     __shared__ uint32_t cand[2 * PM_CAND_MAX * TRACE_BLOCK];     // units, then t lower bounds
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR(ANY, MIXED) void trace_ke
         }
     };
     pmd::trace_persistent<ANY, COUNT, MIXED>(nodes, prims, n, work, refill, stack + threadIdx.x, cand + threadIdx.x, TRACE_BLOCK,
-                                      defer_list, work + PM_WORK_SLOTS, &tc, fetch, commit);
+                                      defer_list, work + PM_WORK_SLOTS, defer_cap, &tc, fetch, commit);
     if (COUNT) {
         // wave-level reduction, one atomic per wave per counter
         unsigned long long nn = tc.nodes, pp = tc.prims, ee = tc.exact, ff = tc.fallback;
@@ -52,7 +52,7 @@ template <bool ANY, bool COUNT, bool PATCH>
 __global__ __launch_bounds__(TRACE_BLOCK) PM_FLAT_ATTR void trace_flat_kernel(PmFlatScene fs, const uint4* __restrict__ prims,
                                                                  const PmRay* __restrict__ rays, uint32_t n,
                                                                  PmHit* __restrict__ hits, uint8_t* __restrict__ occ,
-                                                                 uint4* __restrict__ defer_list, uint32_t* __restrict__ defer_count,
+                                                                 uint4* __restrict__ defer_list, uint32_t defer_cap, uint32_t* __restrict__ defer_count,
                                                                  uint32_t* __restrict__ slow_list,
                                                                  unsigned long long* __restrict__ counters) {
     __shared__ uint32_t cand[3 * PM_FLAT_CAND_MAX * TRACE_BLOCK];     // units, then the lower bounds of t as fractions (numerators, denominators)
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PM_FLAT_ATTR void trace_flat_kernel(Pm
         }
     };
     pmd::trace_flat<ANY, COUNT, PATCH>(fs, prims, n, cand + threadIdx.x, TRACE_BLOCK, defer_list, defer_count, slow_list,
-                                defer_count + PM_WORK_SLOTS, &tc, fetch, commit);
+                                defer_count + PM_WORK_SLOTS, defer_cap, &tc, fetch, commit);
     if (COUNT) {
         unsigned long long pp = tc.prims, ee = tc.exact, ff = tc.fallback;
         for (int off = 32; off > 0; off >>= 1) { pp += __shfl_down(pp, off); ee += __shfl_down(ee, off); ff += __shfl_down(ff, off); }
@@ -81,13 +81,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) PM_FLAT_ATTR void trace_flat_kernel(Pm
             if (ff) atomicAdd(&counters[7], ff);
         }
     }
+    if (tc.overflow) atomicAdd(&counters[3], 1ull);
 }
 
 // second pass (pm_device.hpp deferred_fix): exact tests of what trace_kernel / trace_flat_kernel deferred, dense waves
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_fix_kernel(PmFlatScene fs, const uint4* __restrict__ prims, const PmRay* __restrict__ rays,
                                                                 PmHit* __restrict__ hits, uint8_t* __restrict__ occ,
-                                                                const uint4* __restrict__ defer_list,
+                                                                const uint4* __restrict__ defer_list, uint32_t defer_cap,
                                                                 const uint32_t* __restrict__ defer_count,
                                                                 const uint32_t* __restrict__ slow_list,
                                                                 unsigned long long* __restrict__ counters) {
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_fix_kernel(PmFlatScene fs, 
         }
     };
     __shared__ uint4 gather[128 * (TRACE_BLOCK / 64)];
-    pmd::deferred_fix<ANY, COUNT>(fs, prims, defer_list, defer_count, slow_list, defer_count + PM_WORK_SLOTS,
+    pmd::deferred_fix<ANY, COUNT>(fs, prims, defer_list, defer_count, slow_list, defer_count + PM_WORK_SLOTS, defer_cap,
                                   gather + 128 * (threadIdx.x >> 6), &tc, fetch, load_t, commit);
     if (COUNT && tc.exact) atomicAdd(&counters[6], (unsigned long long)tc.exact);
     if (COUNT && tc.prims) atomicAdd(&counters[2], (unsigned long long)tc.prims);
@@ -213,7 +214,7 @@ extern "C" int pm_add_spheres(pm_ctx* c, const PmSphere* s, uint32_t n, uint32_t
         }
         c->scene.spheres.push_back(h);
     }
-    c->accel_valid = false;
+    c->accel_valid = false; c->geom_gen++;
     return PM_OK;
 }
 
@@ -234,7 +235,7 @@ extern "C" int pm_add_patch_mesh(pm_ctx* c, const float* pos, uint32_t n_vert, c
         h.bounds = box_of_points(h.p, 4);   // bilinear_patch.rs:176-181
         c->scene.patches.push_back(h);
     }
-    c->accel_valid = false;
+    c->accel_valid = false; c->geom_gen++;
     return PM_OK;
 }
 
@@ -252,14 +253,14 @@ extern "C" int pm_add_triangle_mesh(pm_ctx* c, const float* pos, uint32_t n_vert
         h.bounds = box_of_points(h.v, 3);
         c->scene.tris.push_back(h);
     }
-    c->accel_valid = false;
+    c->accel_valid = false; c->geom_gen++;
     return PM_OK;
 }
 
 extern "C" int pm_clear_geometry(pm_ctx* c) {
     if (!c) return PM_ERR_INVALID;
     c->scene = pm::HostScene();
-    c->accel_valid = false;
+    c->accel_valid = false; c->geom_gen++;
     return PM_OK;
 }
 
@@ -309,7 +310,7 @@ extern "C" int pm_build_accel(pm_ctx* c, int split_method, int max_prims_in_node
         if (!c->accel.flat_units.empty()) HIPCHK(c, hipMemcpy(du, c->accel.flat_units.data(), c->accel.flat_units.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         c->flat = PmFlatScene{dt, du, c->accel.flat_n[0], c->accel.flat_n[1], c->accel.flat_n[2]};
     }
-    c->accel_valid = true;
+    c->accel_valid = true; c->geom_gen++;
     // refill threshold of the persistent traversal waves: walks through a tiny tree all have about the same (short)
     // length, so refilling early only multiplies the exact-test rounds; deep trees have long-tailed walks.
     c->refill = n_nodes <= 64 ? 64u : 24u;     // measured: scripts/refill_sweep.sh, profiles/r01/refill_sweep*.log
@@ -331,6 +332,40 @@ extern "C" int pm_build_accel(pm_ctx* c, int split_method, int max_prims_in_node
 }
 
 // ------------------------------------------------------------------------------------------ trace
+// the kernels of one batch of at most 2^30 rays that are resident in HBM: walk (or flat sweep) + second pass.  `work` holds
+// 3 * PM_WORK_SLOTS zeroed counters (work items, deferred entries, slow entries), `slot` picks this launch's; max_blocks
+// bounds the grids (the lists must hold items + waves * PM_DEFER_CHUNK entries, pm_device.hpp DeferWriter).
+template <bool ANY>
+static void launch_trace(pm_ctx* c, const PmRay* d_rays, uint32_t m, PmHit* oh, uint8_t* oo, uint32_t* work, uint32_t slot,
+                         uint4* defer, uint32_t defer_cap, uint32_t* slow, unsigned long long* counters, bool counting,
+                         uint32_t max_blocks) {
+    const bool has_spheres = !c->scene.spheres.empty();
+    const uint32_t blocks = (m + TRACE_BLOCK - 1) / TRACE_BLOCK;
+    const uint32_t grid = std::min(std::min<uint32_t>(blocks, (uint32_t)c->n_cu * PM_BLOCKS_PER_CU), max_blocks);
+    if (c->flat.tris) {
+        const uint32_t fgrid = std::min(std::min<uint32_t>(blocks, (uint32_t)c->n_cu * PM_FLAT_BLOCKS_PER_CU), max_blocks);
+        const bool patch = c->flat.n_patch > 0;
+        auto kernel = counting ? (patch ? trace_flat_kernel<ANY, true, true> : trace_flat_kernel<ANY, true, false>)
+                               : (patch ? trace_flat_kernel<ANY, false, true> : trace_flat_kernel<ANY, false, false>);
+        hipLaunchKernelGGL(kernel, dim3(fgrid), dim3(TRACE_BLOCK), 0, c->stream, c->flat, c->d_prims, d_rays, m, oh, oo,
+                           defer, defer_cap, work + PM_WORK_SLOTS + slot, slow, counters);
+    } else {
+        const bool mixed = has_spheres || !c->scene.patches.empty();
+        auto kernel = counting ? (mixed ? trace_kernel<ANY, true, true> : trace_kernel<ANY, true, false>)
+                               : (mixed ? trace_kernel<ANY, false, true> : trace_kernel<ANY, false, false>);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_nodes, c->d_prims, d_rays, m, oh, oo,
+                           work + slot, c->refill, defer, defer_cap, counters);
+    }
+    if (has_spheres || c->flat.tris) {      // the flat sweep defers patches and rare cases too
+        if (counting)
+            hipLaunchKernelGGL((trace_fix_kernel<ANY, true>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->flat, c->d_prims,
+                               d_rays, oh, oo, defer, defer_cap, work + PM_WORK_SLOTS + slot, c->flat.tris ? slow : nullptr, counters);
+        else
+            hipLaunchKernelGGL((trace_fix_kernel<ANY, false>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->flat, c->d_prims,
+                               d_rays, oh, oo, defer, defer_cap, work + PM_WORK_SLOTS + slot, c->flat.tris ? slow : nullptr, counters);
+    }
+}
+
 template <bool ANY>
 static int trace_impl(pm_ctx* c, const PmRay* rays, uint64_t n, void* out, size_t out_elem) {
     if (!c) return PM_ERR_INVALID;
@@ -367,33 +402,10 @@ static int trace_impl(pm_ctx* c, const PmRay* rays, uint64_t n, void* out, size_
         if (slot == 0) HIPCHK(c, hipMemsetAsync(c->d_work, 0, 3 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
         const uint64_t b = k * chunk;
         const uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - b);
-        const uint32_t grid = std::min<uint32_t>((m + TRACE_BLOCK - 1) / TRACE_BLOCK, (uint32_t)c->n_cu * PM_BLOCKS_PER_CU);
         PmHit* oh = ANY ? nullptr : (PmHit*)d_out + b;
         uint8_t* oo = ANY ? (uint8_t*)d_out + b : nullptr;
-        if (c->flat.tris) {
-            const uint32_t fgrid = std::min<uint32_t>((m + TRACE_BLOCK - 1) / TRACE_BLOCK, (uint32_t)c->n_cu * PM_FLAT_BLOCKS_PER_CU);
-            const bool patch = c->flat.n_patch > 0;
-            auto kernel = c->counting ? (patch ? trace_flat_kernel<ANY, true, true> : trace_flat_kernel<ANY, true, false>)
-                                      : (patch ? trace_flat_kernel<ANY, false, true> : trace_flat_kernel<ANY, false, false>);
-            hipLaunchKernelGGL(kernel, dim3(fgrid), dim3(TRACE_BLOCK), 0, c->stream, c->flat, c->d_prims, d_rays + b, m, oh, oo,
-                               c->d_defer, c->d_work + PM_WORK_SLOTS + slot, c->d_slow, c->d_counters);
-        } else {
-            const bool mixed = has_spheres || !c->scene.patches.empty();
-            auto kernel = c->counting ? (mixed ? trace_kernel<ANY, true, true> : trace_kernel<ANY, true, false>)
-                                      : (mixed ? trace_kernel<ANY, false, true> : trace_kernel<ANY, false, false>);
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_nodes, c->d_prims, d_rays + b, m, oh, oo,
-                               c->d_work + slot, c->refill, c->d_defer, c->d_counters);
-        }
-        if (has_spheres || c->flat.tris) {      // the flat sweep defers patches and rare cases too
-            if (c->counting)
-                hipLaunchKernelGGL((trace_fix_kernel<ANY, true>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->flat, c->d_prims,
-                                   d_rays + b, oh, oo, c->d_defer, c->d_work + PM_WORK_SLOTS + slot, c->flat.tris ? c->d_slow : nullptr,
-                                   c->d_counters);
-            else
-                hipLaunchKernelGGL((trace_fix_kernel<ANY, false>), dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->flat, c->d_prims,
-                                   d_rays + b, oh, oo, c->d_defer, c->d_work + PM_WORK_SLOTS + slot, c->flat.tris ? c->d_slow : nullptr,
-                                   c->d_counters);
-        }
+        launch_trace<ANY>(c, d_rays + b, m, oh, oo, c->d_work, slot, c->d_defer, (uint32_t)c->defer_cap, c->d_slow, c->d_counters,
+                          c->counting, 0xFFFFFFFFu);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
@@ -403,7 +415,7 @@ static int trace_impl(pm_ctx* c, const PmRay* rays, uint64_t n, void* out, size_
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
     if (c->counting) c->rays_counted += n;
-    if (after[3] != before[3]) return fail(c, PM_ERR_STACK_OVERFLOW, "trace: traversal stack overflow");
+    if (after[3] != before[3]) return fail(c, PM_ERR_STACK_OVERFLOW, "trace: traversal stack / deferred list overflow");
     return PM_OK;
 }
 extern "C" int pm_trace_closest(pm_ctx* c, const PmRay* rays, uint64_t n, PmHit* out) {

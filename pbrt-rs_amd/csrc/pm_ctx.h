@@ -52,6 +52,8 @@ struct pm_ctx {
     pm::HostScene scene;
     pm::Accel accel;
     bool accel_valid = false;
+    uint64_t geom_gen = 0;                      // bumped by every geometry mutation and every pm_build_accel: the render state
+                                                // re-uploads its per-primitive tables when it has seen an older generation
     int split_method = PM_SPLIT_SAH;
     PmWideNode* d_nodes = nullptr;
     uint4* d_prims = nullptr;

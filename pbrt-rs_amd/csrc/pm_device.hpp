@@ -351,55 +351,70 @@ PMD bool sphere_prefilter(f3 ro, f3 rd, float R, float D, const float* m, float 
 
 // Appending to the deferred-sphere list.  One atomic per wave per append on a single counter serialises (measured: ~5 ns
 // each, as much time as the whole sweep of the C2 scene), so a wave reserves PM_DEFER_CHUNK entries at a time and fills
-// them itself; what is left of a reservation is padded with invalid entries (item == ~0) that the second pass skips.
-// The list therefore needs room for items + waves * PM_DEFER_CHUNK entries (pm_ctx.h ensure_defer).  All members are
-// wave-uniform: call push / finish from wave-uniform control flow only.
+// them itself: a push that does not fit fills the rest of the current reservation, reserves the next chunk and puts the
+// remaining lanes there, so only a wave's LAST reservation is left partly unused; finish pads that with invalid entries
+// (item == ~0) that the second pass skips.  The list therefore needs room for items + waves * PM_DEFER_CHUNK entries
+// (pm_ctx.h ensure_defer).  `cap` (entries) is checked at every reservation: a reservation beyond it is not written and
+// sets *overflow (reported like a traversal-stack overflow: results invalid), so the list can never be overrun.  All
+// members are wave-uniform: call push / pad from wave-uniform control flow only.
 #define PM_DEFER_CHUNK 256u
 struct DeferWriter {
-    uint4* list; uint32_t* count; uint32_t next, end;
+    uint4* list; uint32_t* count; uint32_t next, end, cap;
     PMD void pad(uint32_t lane) {
         for (uint32_t i = next + lane; i < end; i += 64u) list[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u);
         next = end;
     }
-    PMD void push(bool defer, uint32_t lane, uint32_t item, uint32_t s0, uint32_t s1, uint32_t s2) {
+    PMD void push(bool defer, uint32_t lane, uint32_t item, uint32_t s0, uint32_t s1, uint32_t s2, uint32_t* overflow) {
         const unsigned long long dm = __ballot(defer);
         const uint32_t n = (uint32_t)__popcll(dm);
         if (n == 0u) return;
-        if (next + n > end) {
-            pad(lane);
-            uint32_t base = 0;
-            if (lane == 0u) base = atomicAdd(count, PM_DEFER_CHUNK);
-            next = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);       // a scalar register, not 64 copies
-            end = next + PM_DEFER_CHUNK;
+        const uint32_t rank = (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
+        const uint32_t room = end - next;
+        if (n <= room) {
+            if (defer) list[next + rank] = make_uint4(item, s0, s1, s2);
+            next += n;
+            return;
         }
-        if (defer) list[next + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = make_uint4(item, s0, s1, s2);
-        next += n;
+        if (defer && rank < room) list[next + rank] = make_uint4(item, s0, s1, s2);
+        uint32_t base = 0;
+        if (lane == 0u) base = atomicAdd(count, PM_DEFER_CHUNK);
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);       // a scalar register, not 64 copies
+        if (base + PM_DEFER_CHUNK > cap || base + PM_DEFER_CHUNK < base) {          // no room left: drop, report
+            *overflow = 1u;
+            next = 0u; end = 0u;
+            return;
+        }
+        if (defer && rank >= room) list[base + (rank - room)] = make_uint4(item, s0, s1, s2);
+        next = base + (n - room); end = base + PM_DEFER_CHUNK;
     }
 };
 
-// the same for the (rare) slow rays of the flat sweep: a list of work items, 8 reserved at a time (little padding: the
-// second pass sweeps the whole table for them, so its waves must be full), padding = ~0
-#define PM_SLOW_CHUNK 8u
+// the same for the (rare) slow rays of the flat sweep: a list of work items, 64 reserved at a time, padding = ~0
+#define PM_SLOW_CHUNK 64u
 struct SlowWriter {
-    uint32_t* list; uint32_t* count; uint32_t next, end;
+    uint32_t* list; uint32_t* count; uint32_t next, end, cap;
     PMD void pad(uint32_t lane) {
         for (uint32_t i = next + lane; i < end; i += 64u) list[i] = 0xFFFFFFFFu;
         next = end;
     }
-    PMD void push(bool slow, uint32_t lane, uint32_t item) {
+    PMD void push(bool slow, uint32_t lane, uint32_t item, uint32_t* overflow) {
         const unsigned long long dm = __ballot(slow);
         const uint32_t n = (uint32_t)__popcll(dm);
         if (n == 0u) return;
-        if (next + n > end) {
-            pad(lane);
-            uint32_t base = 0;
-            const uint32_t reserve = ((n + PM_SLOW_CHUNK - 1u) / PM_SLOW_CHUNK) * PM_SLOW_CHUNK;      // n may exceed a chunk
-            if (lane == 0u) base = atomicAdd(count, reserve);
-            next = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);       // a scalar register, not 64 copies
-            end = next + reserve;
+        const uint32_t rank = (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
+        const uint32_t room = end - next;
+        if (n <= room) {
+            if (slow) list[next + rank] = item;
+            next += n;
+            return;
         }
-        if (slow) list[next + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = item;
-        next += n;
+        if (slow && rank < room) list[next + rank] = item;
+        uint32_t base = 0;
+        if (lane == 0u) base = atomicAdd(count, PM_SLOW_CHUNK);
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
+        if (base + PM_SLOW_CHUNK > cap || base + PM_SLOW_CHUNK < base) { *overflow = 1u; next = 0u; end = 0u; return; }
+        if (slow && rank >= room) list[base + (rank - room)] = item;
+        next = base + (n - room); end = base + PM_SLOW_CHUNK;
     }
 };
 
@@ -436,7 +451,7 @@ PMD float safe_rcp_dir(float d) { return fabsf(d) < 1e-18f ? copysignf(1e18f, d)
 template <bool ANY, bool COUNT, bool MIXED, class FetchFn, class CommitFn>
 PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __restrict__ prims, uint32_t n_items,
                           uint32_t* __restrict__ work_counter, uint32_t refill, uint2* lds, uint32_t* cand, int stride,
-                          uint4* __restrict__ defer_list, uint32_t* __restrict__ defer_count,
+                          uint4* __restrict__ defer_list, uint32_t* __restrict__ defer_count, uint32_t defer_cap,
                           TravCounters* ctr, FetchFn fetch, CommitFn commit) {
     const float widen = 1.0f + 2.0f * gamma_n(3);
     const uint32_t lane = threadIdx.x & 63u;
@@ -485,7 +500,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
     uint32_t chunk = n_items / (gridDim.x * (blockDim.x >> 6) * 16u);
     chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : (chunk & ~63u));
     uint32_t wnext = 0, wend = 0;
-    DeferWriter dw; dw.list = defer_list; dw.count = defer_count; dw.next = 0u; dw.end = 0u;
+    DeferWriter dw; dw.list = defer_list; dw.count = defer_count; dw.next = 0u; dw.end = 0u; dw.cap = defer_cap;
 
     for (;;) {
         const uint32_t n_idle = (uint32_t)__popcll(__ballot(!active));
@@ -521,7 +536,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                     if (!ANY || !defer) commit(item, found, hit);
                 } else { exact_mode = true; if (COUNT) ctr->fallback++; start_walk(); }
             }
-            if (MIXED) dw.push(defer, lane, item, sph0, sph1, 0xFFFFFFFFu);      // wave-uniform control flow here
+            if (MIXED) dw.push(defer, lane, item, sph0, sph1, 0xFFFFFFFFu, &ctr->overflow);      // wave-uniform control flow here
             // ---- idle lanes fetch the next items
             if (wnext >= wend && more) {
                 uint32_t base = 0;
@@ -745,11 +760,11 @@ PMD cuint_p as_uniform(const uint32_t* p) { return (cuint_p)p; }
 template <bool ANY, bool COUNT, bool PATCH, class FetchFn, class CommitFn>
 PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_items, uint32_t* cand, int stride,
                     uint4* __restrict__ defer_list, uint32_t* __restrict__ defer_count, uint32_t* __restrict__ slow_list,
-                    uint32_t* __restrict__ slow_count, TravCounters* ctr, FetchFn fetch, CommitFn commit) {
+                    uint32_t* __restrict__ slow_count, uint32_t defer_cap, TravCounters* ctr, FetchFn fetch, CommitFn commit) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-    DeferWriter dw; dw.list = defer_list; dw.count = defer_count; dw.next = 0u; dw.end = 0u;
-    SlowWriter sw; sw.list = slow_list; sw.count = slow_count; sw.next = 0u; sw.end = 0u;
+    DeferWriter dw; dw.list = defer_list; dw.count = defer_count; dw.next = 0u; dw.end = 0u; dw.cap = defer_cap;
+    SlowWriter sw; sw.list = slow_list; sw.count = slow_count; sw.next = 0u; sw.end = 0u; sw.cap = defer_cap;
     for (uint32_t base = wave * 64u; base < n_items; base += n_waves * 64u) {
         const uint32_t item = base + lane;
         Ray ray; ray.o = mk3(0.f, 0.f, 0.f); ray.d = mk3(0.f, 0.f, 1.f); ray.tmax = 0.f;
@@ -881,8 +896,8 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
         const bool redo = live && (slow || unconfirmed);
         const bool pass2 = live && !redo && d0 != PM_DEFER_NONE && !(ANY && found);
         if (live && !redo && (!ANY || !pass2)) commit(item, found, hit);
-        dw.push(pass2, lane, item, d0, d1, d2);
-        sw.push(redo, lane, item);
+        dw.push(pass2, lane, item, d0, d1, d2, &ctr->overflow);
+        sw.push(redo, lane, item, &ctr->overflow);
     }
     dw.pad(lane);
     sw.pad(lane);
@@ -943,9 +958,9 @@ PMD void fix_test_patch(const uint4* __restrict__ prims, uint32_t unit, bool is_
 template <bool ANY, bool COUNT, class FetchFn, class LoadTFn, class CommitFn>
 PMD void deferred_fix(FlatScene fs, const uint4* __restrict__ prims, const uint4* __restrict__ defer_list,
                       const uint32_t* __restrict__ defer_count, const uint32_t* __restrict__ slow_list,
-                      const uint32_t* __restrict__ slow_count, uint4* buf, TravCounters* ctr, FetchFn fetch, LoadTFn load_t,
-                      CommitFn commit) {
-    const uint32_t n = *defer_count;
+                      const uint32_t* __restrict__ slow_count, uint32_t defer_cap, uint4* buf, TravCounters* ctr, FetchFn fetch,
+                      LoadTFn load_t, CommitFn commit) {
+    const uint32_t n = *defer_count < defer_cap ? *defer_count : defer_cap;      // (an overflowing pass 1 has reported itself)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     uint32_t cnt = 0;                                   // wave-uniform: valid entries waiting in buf
@@ -985,7 +1000,7 @@ PMD void deferred_fix(FlatScene fs, const uint4* __restrict__ prims, const uint4
     }
     // ---- slow rays (flat sweep only): everything, exactly.  Same gathering, in the first 128 words of buf.
     if (slow_list == nullptr) return;
-    const uint32_t ns = *slow_count;
+    const uint32_t ns = *slow_count < defer_cap ? *slow_count : defer_cap;
     uint32_t* ibuf = reinterpret_cast<uint32_t*>(buf);
     cnt = 0;
     for (uint32_t base = wave * 64u; base < ns || cnt > 0u; base += n_waves * 64u) {

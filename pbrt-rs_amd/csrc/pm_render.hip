@@ -112,7 +112,7 @@ __global__ __launch_bounds__(RB) void raygen_kernel(RenderConst rc, SceneArrays 
 template <bool COUNT, bool MIXED>
 __global__ __launch_bounds__(TB) PM_TRAV_ATTR(false, MIXED) void closest_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
                                                      const uint32_t* __restrict__ count, uint32_t* __restrict__ work, uint32_t refill,
-                                                     uint4* __restrict__ defer_list, unsigned long long* __restrict__ counters) {
+                                                     uint4* __restrict__ defer_list, uint32_t defer_cap, unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
     __shared__ uint32_t cand[2 * PM_CAND_MAX * TB];     // units, then t lower bounds
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR(false, MIXED) void closest_kernel(
         pa.hit[queue[i]] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
     };
     trace_persistent<false, COUNT, MIXED>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB,
-                                   defer_list, work + PM_WORK_SLOTS, &tc, fetch, commit);
+                                   defer_list, work + PM_WORK_SLOTS, defer_cap, &tc, fetch, commit);
     if (COUNT) {
         atomicAdd(&counters[1], (unsigned long long)tc.nodes); atomicAdd(&counters[2], (unsigned long long)tc.prims);
         atomicAdd(&counters[6], (unsigned long long)tc.exact); if (tc.fallback) atomicAdd(&counters[7], (unsigned long long)tc.fallback);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR(false, MIXED) void closest_kernel(
 }
 template <bool COUNT, bool MIXED>
 __global__ __launch_bounds__(TB) PM_TRAV_ATTR(true, MIXED) void shadow_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ count,
-                                                    uint32_t* __restrict__ work, uint32_t refill, uint4* __restrict__ defer_list,
+                                                    uint32_t* __restrict__ work, uint32_t refill, uint4* __restrict__ defer_list, uint32_t defer_cap,
                                                     unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
     __shared__ uint32_t cand[2 * PM_CAND_MAX * TB];     // units, then t lower bounds
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR(true, MIXED) void shadow_kernel(Sc
         }
     };
     trace_persistent<true, COUNT, MIXED>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB,
-                                  defer_list, work + PM_WORK_SLOTS, &tc, fetch, commit);
+                                  defer_list, work + PM_WORK_SLOTS, defer_cap, &tc, fetch, commit);
     if (COUNT) {
         atomicAdd(&counters[4], (unsigned long long)tc.nodes); atomicAdd(&counters[5], (unsigned long long)tc.prims);
         atomicAdd(&counters[6], (unsigned long long)tc.exact); if (tc.fallback) atomicAdd(&counters[7], (unsigned long long)tc.fallback);
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR(true, MIXED) void shadow_kernel(Sc
 // flat-sweep variants for scenes of at most PM_FLAT_MAX_PRIMS primitives (pm_device.hpp trace_flat)
 template <bool COUNT, bool PATCH>
 __global__ __launch_bounds__(TB) PM_FLAT_ATTR void closest_flat_kernel(PmFlatScene fs, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
-                                                          const uint32_t* __restrict__ count, uint4* __restrict__ defer_list,
+                                                          const uint32_t* __restrict__ count, uint4* __restrict__ defer_list, uint32_t defer_cap,
                                                           uint32_t* __restrict__ defer_count, uint32_t* __restrict__ slow_list,
                                                           unsigned long long* __restrict__ counters) {
     __shared__ uint32_t cand[3 * PM_FLAT_CAND_MAX * TB];     // units, then the lower bounds of t as fractions (numerators, denominators)
@@ -185,15 +185,16 @@ __global__ __launch_bounds__(TB) PM_FLAT_ATTR void closest_flat_kernel(PmFlatSce
         pa.hit[queue[i]] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
     };
     trace_flat<false, COUNT, PATCH>(fs, sc.prims, *count, cand + threadIdx.x, TB, defer_list, defer_count, slow_list,
-                             defer_count + PM_WORK_SLOTS, &tc, fetch, commit);
+                             defer_count + PM_WORK_SLOTS, defer_cap, &tc, fetch, commit);
     if (COUNT) {
         atomicAdd(&counters[2], (unsigned long long)tc.prims); atomicAdd(&counters[6], (unsigned long long)tc.exact);
         if (tc.fallback) atomicAdd(&counters[7], (unsigned long long)tc.fallback);
     }
+    if (tc.overflow) atomicAdd(&counters[3], 1ull);
 }
 template <bool COUNT, bool PATCH>
 __global__ __launch_bounds__(TB) PM_FLAT_ATTR void shadow_flat_kernel(PmFlatScene fs, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ count,
-                                                         uint4* __restrict__ defer_list, uint32_t* __restrict__ defer_count,
+                                                         uint4* __restrict__ defer_list, uint32_t defer_cap, uint32_t* __restrict__ defer_count,
                                                          uint32_t* __restrict__ slow_list, unsigned long long* __restrict__ counters) {
     __shared__ uint32_t cand[3 * PM_FLAT_CAND_MAX * TB];     // units, then the lower bounds of t as fractions (numerators, denominators)
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
@@ -213,16 +214,17 @@ __global__ __launch_bounds__(TB) PM_FLAT_ATTR void shadow_flat_kernel(PmFlatScen
         }
     };
     trace_flat<true, COUNT, PATCH>(fs, sc.prims, *count, cand + threadIdx.x, TB, defer_list, defer_count, slow_list,
-                            defer_count + PM_WORK_SLOTS, &tc, fetch, commit);
+                            defer_count + PM_WORK_SLOTS, defer_cap, &tc, fetch, commit);
     if (COUNT) {
         atomicAdd(&counters[5], (unsigned long long)tc.prims); atomicAdd(&counters[6], (unsigned long long)tc.exact);
         if (tc.fallback) atomicAdd(&counters[7], (unsigned long long)tc.fallback);
     }
+    if (tc.overflow) atomicAdd(&counters[3], 1ull);
 }
 // second pass (pm_device.hpp deferred_fix): exact tests of what the kernels above deferred, with the same fetch / commit
 template <bool COUNT>
 __global__ __launch_bounds__(TB) void closest_fix_kernel(PmFlatScene fs, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
-                                                         const uint4* __restrict__ defer_list, const uint32_t* __restrict__ defer_count,
+                                                         const uint4* __restrict__ defer_list, uint32_t defer_cap, const uint32_t* __restrict__ defer_count,
                                                          const uint32_t* __restrict__ slow_list, unsigned long long* __restrict__ counters) {
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
@@ -236,13 +238,13 @@ __global__ __launch_bounds__(TB) void closest_fix_kernel(PmFlatScene fs, SceneAr
         pa.hit[queue[i]] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
     };
     __shared__ uint4 gather[128 * (TB / 64)];
-    deferred_fix<false, COUNT>(fs, sc.prims, defer_list, defer_count, slow_list, defer_count + PM_WORK_SLOTS,
+    deferred_fix<false, COUNT>(fs, sc.prims, defer_list, defer_count, slow_list, defer_count + PM_WORK_SLOTS, defer_cap,
                                gather + 128 * (threadIdx.x >> 6), &tc, fetch, load_t, commit);
     if (COUNT && tc.exact) atomicAdd(&counters[6], (unsigned long long)tc.exact);
     if (COUNT && tc.prims) atomicAdd(&counters[2], (unsigned long long)tc.prims);
 }
 template <bool COUNT>
-__global__ __launch_bounds__(TB) void shadow_fix_kernel(PmFlatScene fs, SceneArrays sc, PathArrays pa, const uint4* __restrict__ defer_list,
+__global__ __launch_bounds__(TB) void shadow_fix_kernel(PmFlatScene fs, SceneArrays sc, PathArrays pa, const uint4* __restrict__ defer_list, uint32_t defer_cap,
                                                         const uint32_t* __restrict__ defer_count, const uint32_t* __restrict__ slow_list,
                                                         unsigned long long* __restrict__ counters) {
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(TB) void shadow_fix_kernel(PmFlatScene fs, SceneArr
         }
     };
     __shared__ uint4 gather[128 * (TB / 64)];
-    deferred_fix<true, COUNT>(fs, sc.prims, defer_list, defer_count, slow_list, defer_count + PM_WORK_SLOTS,
+    deferred_fix<true, COUNT>(fs, sc.prims, defer_list, defer_count, slow_list, defer_count + PM_WORK_SLOTS, defer_cap,
                               gather + 128 * (threadIdx.x >> 6), &tc, fetch, load_t, commit);
     if (COUNT && tc.exact) atomicAdd(&counters[6], (unsigned long long)tc.exact);
     if (COUNT && tc.prims) atomicAdd(&counters[5], (unsigned long long)tc.prims);
@@ -618,7 +620,7 @@ struct RenderState {
     PmFilm film{}; bool have_film = false;
     std::vector<float> sensor, filter_vals;
     // device
-    bool scene_dirty = true; const void* accel_tag = nullptr;
+    bool scene_dirty = true; uint64_t geom_gen = ~0ull;     // pm_ctx::geom_gen the tables were uploaded for
     float* d_pool = nullptr; DMaterial* d_mats = nullptr; DLight* d_lights = nullptr; int* d_inf = nullptr;
     uint32_t *d_prim_mat = nullptr, *d_prim_ref = nullptr; DShadePatch* d_patches = nullptr; DShadeSphere* d_spheres = nullptr;
     float* d_m9 = nullptr;
@@ -851,7 +853,7 @@ static int upload_scene(pm_ctx* c, RenderState* r) {
     if ((rc = upload(c, &r->d_patches, sp))) return rc;
     if ((rc = upload(c, &r->d_spheres, ss))) return rc;
     r->scene_dirty = false;
-    r->accel_tag = c->d_nodes;
+    r->geom_gen = c->geom_gen;
     return PM_OK;
 }
 
@@ -893,7 +895,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     if (s0 < 0 || s1 > p->spp || s0 > s1) return fail(c, PM_ERR_INVALID, "pm_render: sample window outside [0, spp)");
     HIPCHK(c, hipSetDevice(c->device));
     int rcode;
-    if (r->scene_dirty || r->accel_tag != c->d_nodes) if ((rcode = upload_scene(c, r))) return rcode;
+    if (r->scene_dirty || r->geom_gen != c->geom_gen) if ((rcode = upload_scene(c, r))) return rcode;
     r->stats = PmRenderStats{};
     r->stats.state_bytes_per_path = 10 * 16 + 16 + 8 + 12;
     const int W = x1 - x0, H = y1 - y0;
@@ -975,15 +977,15 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
             if (flat) {
                 auto kernel = c->counting ? (fpatch ? closest_flat_kernel<true, true> : closest_flat_kernel<true, false>)
                                           : (fpatch ? closest_flat_kernel<false, true> : closest_flat_kernel<false, false>);
-                hipLaunchKernelGGL(kernel, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, qin, cnt_in, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_slow, c->d_counters);
+                hipLaunchKernelGGL(kernel, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, qin, cnt_in, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, c->d_slow, c->d_counters);
             } else {
                 auto kernel = c->counting ? (mixed ? closest_kernel<true, true> : closest_kernel<true, false>)
                                           : (mixed ? closest_kernel<false, true> : closest_kernel<false, false>);
-                hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_work + wslot, c->refill, c->d_defer, c->d_counters);
+                hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_work + wslot, c->refill, c->d_defer, (uint32_t)c->defer_cap, c->d_counters);
             }
             if (has_spheres || flat) {     // second pass: dense exact tests of what was deferred (timed with the closest-hit class)
-                if (c->counting) hipLaunchKernelGGL(closest_fix_kernel<true>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, qin, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
-                else hipLaunchKernelGGL(closest_fix_kernel<false>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, qin, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
+                if (c->counting) hipLaunchKernelGGL(closest_fix_kernel<true>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, qin, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
+                else hipLaunchKernelGGL(closest_fix_kernel<false>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, qin, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
             }
             ++wslot;
             mark(2);
@@ -994,15 +996,15 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
                 if (flat) {
                     auto kernel = c->counting ? (fpatch ? shadow_flat_kernel<true, true> : shadow_flat_kernel<true, false>)
                                               : (fpatch ? shadow_flat_kernel<false, true> : shadow_flat_kernel<false, false>);
-                    hipLaunchKernelGGL(kernel, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, cnt_sh, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, c->d_slow, c->d_counters);
+                    hipLaunchKernelGGL(kernel, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, cnt_sh, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, c->d_slow, c->d_counters);
                 } else {
                     auto kernel = c->counting ? (mixed ? shadow_kernel<true, true> : shadow_kernel<true, false>)
                                               : (mixed ? shadow_kernel<false, true> : shadow_kernel<false, false>);
-                    hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_work + wslot, c->refill, c->d_defer, c->d_counters);
+                    hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_work + wslot, c->refill, c->d_defer, (uint32_t)c->defer_cap, c->d_counters);
                 }
                 if (has_spheres || flat) {
-                    if (c->counting) hipLaunchKernelGGL(shadow_fix_kernel<true>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
-                    else hipLaunchKernelGGL(shadow_fix_kernel<false>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, c->d_defer, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
+                    if (c->counting) hipLaunchKernelGGL(shadow_fix_kernel<true>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
+                    else hipLaunchKernelGGL(shadow_fix_kernel<false>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
                 }
                 ++wslot;
             }
