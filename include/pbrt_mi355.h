@@ -114,6 +114,15 @@ int pm_trace_closest(pm_ctx* ctx, const PmRay* rays, uint64_t n, PmHit* out);
 /* BVHAggregate::intersect_p (primitives/aggregates.rs:602-655), n rays -> n bytes (1 = occluded). */
 int pm_trace_any(pm_ctx* ctx, const PmRay* rays, uint64_t n, uint8_t* out);
 
+/* NO COUNTERPART IN THE REFERENCE.  pm_trace_closest for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels and bit-identical results, but it calls no
+ * hipMalloc / hipFree or allocating library routine: the work counters and the deferred-primitive / slow-ray lists of the
+ * kernels live in a file-scope device array of the library (15.8 MB per GPU, held until the process ends).  Limits: at most
+ * PM_NOALLOC_MAX_RAYS rays per call (more -> PM_ERR_INVALID); rays and out must be DEVICE pointers (else PM_ERR_INVALID).
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (from two contexts or threads) race. */
+#define PM_NOALLOC_MAX_RAYS (1u << 18)
+int pm_trace_closest_noalloc(pm_ctx* ctx, const PmRay* d_rays, uint64_t n, PmHit* d_out);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 int pm_set_counting(pm_ctx* ctx, int enabled);      /* counting kernels are slower; off by default */
 int pm_reset_counters(pm_ctx* ctx);

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libpbrt_mi355.so")
 
 PM_OK = 0
 PM_MISS = 0xFFFFFFFF
+PM_NOALLOC_MAX_RAYS = 1 << 18
 PM_SPLIT_HLBVH, PM_SPLIT_SAH, PM_SPLIT_MIDDLE, PM_SPLIT_EQUAL_COUNTS = 0, 1, 2, 3
 
 RAY_DTYPE = np.dtype([("o", "<f4", 3), ("tmax", "<f4"), ("d", "<f4", 3), ("time", "<f4")])
@@ -101,6 +102,7 @@ SYMBOLS = {
     "pm_build_accel": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(PmAccelInfo)]),
     "pm_trace_closest": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "pm_trace_any": (C.c_int, [_P, _P, C.c_uint64, _P]),
+    "pm_trace_closest_noalloc": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "pm_set_counting": (C.c_int, [_P, C.c_int]),
     "pm_reset_counters": (C.c_int, [_P]),
     "pm_get_counters": (C.c_int, [_P, C.POINTER(PmCounters)]),

@@ -123,6 +123,14 @@ class GpuAggregate:
         self._check(self._lib.pm_trace_closest(self._h, rp, n, op))
         return out
 
+    def intersect_noalloc(self, d_rays, d_out):
+        """pm_trace_closest_noalloc: closest hit, device buffers only, at most PM_NOALLOC_MAX_RAYS rays, no allocation."""
+        n = self._count(d_rays)
+        rp, k1 = _ptr(d_rays)
+        op, k2 = _ptr(d_out)
+        self._check(self._lib.pm_trace_closest_noalloc(self._h, rp, n, op))
+        return d_out
+
     def intersect_p(self, rays, out=None):
         """Any hit for every ray -> uint8 array (1 = occluded)."""
         n = self._count(rays)

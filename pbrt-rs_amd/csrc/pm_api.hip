@@ -5,6 +5,24 @@
 #include "pm_ctx.h"
 #include "pm_device.hpp"
 
+// ------------------------------------------------------------------------------------------ scratch of the no-alloc entry point
+// pm_trace_closest_noalloc (include/pbrt_mi355.h) launches the same kernels as pm_trace_closest but allocates nothing: the
+// device memory those kernels need beyond rays and hits - work counters, error counters, the deferred-primitive list and
+// the slow-ray list - lives in this file-scope array.  Every GPU the library runs on holds its own copy until the process
+// ends (15.8 MB).  In host code the NAME `scratch` is only a stand-in for the symbol: the address a kernel can use is looked
+// up once per device with hipGetSymbolAddress (pm_create, with that device current) and kept in g_scratch_ptr[device] /
+// pm_ctx::scratch; host code uses that pointer, never the name.
+#define PM_NA_MAX_BLOCKS 1024u                                                      /* grid bound of the no-alloc launches */
+#define PM_NA_LIST_CAP (PM_NOALLOC_MAX_RAYS + PM_NA_MAX_BLOCKS * (TRACE_BLOCK / 64) * PM_DEFER_CHUNK)   /* entries */
+#define PM_NA_OFF_COUNTERS 1024u                                                    /* 8 x u64 */
+#define PM_NA_OFF_DEFER 4096u                                                       /* uint4[PM_NA_LIST_CAP] */
+#define PM_NA_OFF_SLOW (PM_NA_OFF_DEFER + (size_t)PM_NA_LIST_CAP * 16u)             /* uint32_t[PM_NA_LIST_CAP] */
+#define PM_NA_SCRATCH_BYTES (PM_NA_OFF_SLOW + (size_t)PM_NA_LIST_CAP * 4u)
+static __device__ __align__(256) unsigned char scratch[PM_NA_SCRATCH_BYTES];
+#define PM_MAX_DEVICES 64
+static unsigned char* g_scratch_ptr[PM_MAX_DEVICES];     // per device: each GPU has its own copy at its own address
+static_assert(3 * PM_WORK_SLOTS * sizeof(uint32_t) <= PM_NA_OFF_COUNTERS, "work counters overlap the error counters");
+
 // ------------------------------------------------------------------------------------------ kernels
 template <bool ANY, bool COUNT, bool MIXED>
 __global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR(ANY, MIXED) void trace_kernel(const PmWideNode* __restrict__ nodes,
@@ -139,6 +157,15 @@ extern "C" int pm_create(int device_id, pm_ctx** out) {
         hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) {
         delete c;
         return PM_ERR_HIP;
+    }
+    // device address of this GPU's copy of `scratch` (hipSetDevice(device_id) above made it current)
+    if (device_id < PM_MAX_DEVICES) {
+        if (!g_scratch_ptr[device_id]) {
+            unsigned char* ptr = nullptr;
+            if (hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) { pm_destroy(c); return PM_ERR_HIP; }
+            g_scratch_ptr[device_id] = ptr;
+        }
+        c->scratch = g_scratch_ptr[device_id];
     }
     *out = c;
     return PM_OK;
@@ -423,6 +450,43 @@ extern "C" int pm_trace_closest(pm_ctx* c, const PmRay* rays, uint64_t n, PmHit*
 }
 extern "C" int pm_trace_any(pm_ctx* c, const PmRay* rays, uint64_t n, uint8_t* out) {
     return trace_impl<true>(c, rays, n, out, 1);
+}
+
+// pm_trace_closest for callers that cannot allocate: same kernels, same results, no hipMalloc / hipFree (nor any allocating
+// library routine) - everything the kernels need beyond rays and hits comes from this GPU's `scratch`.  Both buffers must be
+// device memory (a host buffer would need staging, i.e. an allocation).  Calls on one GPU share that GPU's scratch, which
+// keeps the last call's contents: the first 4 KB (work counters, error counters) are cleared here, the lists are rewritten
+// up to the counts the kernels themselves produce.  Calls that overlap on one GPU (two contexts, two threads) race.
+extern "C" int pm_trace_closest_noalloc(pm_ctx* c, const PmRay* rays, uint64_t n, PmHit* out) {
+    if (!c) return PM_ERR_INVALID;
+    if (c->device < 0) return fail(c, PM_ERR_INVALID, "pm_trace_closest_noalloc: host-only context (pm_create(-1)) cannot launch kernels");
+    if (!c->accel_valid) return fail(c, PM_ERR_NO_ACCEL, "pm_trace_closest_noalloc: pm_build_accel has not been called");
+    if (n > PM_NOALLOC_MAX_RAYS)
+        return fail(c, PM_ERR_INVALID, "pm_trace_closest_noalloc: " + std::to_string(n) + " rays exceed PM_NOALLOC_MAX_RAYS (" +
+                                       std::to_string(PM_NOALLOC_MAX_RAYS) + "); split the batch or use pm_trace_closest");
+    if (n == 0) { c->last_ms = 0.f; return PM_OK; }
+    if (!rays || !out) return fail(c, PM_ERR_INVALID, "pm_trace_closest_noalloc: null rays/out");
+    if (!c->scratch) return fail(c, PM_ERR_UNSUPPORTED, "pm_trace_closest_noalloc: no scratch on this device");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!is_device_ptr(rays) || !is_device_ptr(out))
+        return fail(c, PM_ERR_INVALID, "pm_trace_closest_noalloc: rays and out must be device memory (host buffers need staging)");
+    unsigned char* sp = c->scratch;                                 // the looked-up device address, never the symbol's name
+    uint32_t* work = reinterpret_cast<uint32_t*>(sp);
+    unsigned long long* counters = reinterpret_cast<unsigned long long*>(sp + PM_NA_OFF_COUNTERS);
+    uint4* defer = reinterpret_cast<uint4*>(sp + PM_NA_OFF_DEFER);
+    uint32_t* slow = reinterpret_cast<uint32_t*>(sp + PM_NA_OFF_SLOW);
+    HIPCHK(c, hipMemsetAsync(sp, 0, PM_NA_OFF_DEFER, c->stream));    // what must start at zero: work / list / error counters
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    launch_trace<false>(c, rays, (uint32_t)n, out, nullptr, work, 0u, defer, (uint32_t)PM_NA_LIST_CAP, slow, counters, false,
+                        PM_NA_MAX_BLOCKS);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    unsigned long long overflow = 0;
+    HIPCHK(c, hipMemcpyAsync(&overflow, counters + 3, sizeof(overflow), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    if (overflow) return fail(c, PM_ERR_STACK_OVERFLOW, "pm_trace_closest_noalloc: traversal stack / deferred list overflow");
+    return PM_OK;
 }
 
 // ------------------------------------------------------------------------------------------ measurement

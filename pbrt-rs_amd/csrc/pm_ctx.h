@@ -73,6 +73,7 @@ struct pm_ctx {
     // staging for host-pointer callers
     void* d_stage_in = nullptr; size_t stage_in_cap = 0;
     void* d_stage_out = nullptr; size_t stage_out_cap = 0;
+    unsigned char* scratch = nullptr;   // device address of this GPU's file-scope scratch array (pm_api.hip; not owned)
     RenderState* render = nullptr;   // owned; created lazily by the render entry points
 };
 void pm_render_state_destroy(pm_ctx* c);
