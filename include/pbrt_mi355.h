@@ -230,6 +230,11 @@ int pm_get_render_stats(pm_ctx* ctx, PmRenderStats* out);
  * on the device with the same kernels (13 floats) */
 int pm_debug_sample(pm_ctx* ctx, const PmRenderParams* params, int32_t px, int32_t py, int32_t sample_index, float* out13);
 
+/* test hook: the first n uniforms that IndependentSampler::get_1d returns after start_pixel_sample((px,py), sample_index,
+ * dimension) with this seed (sampling/sampler.rs:104-124, util/rng.rs:15-50), drawn by the device's PCG32 / murmur3 code */
+int pm_debug_uniforms(pm_ctx* ctx, int32_t px, int32_t py, uint32_t seed, uint64_t sample_index, uint64_t dimension, int32_t n,
+                      float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,7 @@ def lib():
             "ora_hash_pixel": (u64, [C.c_int32, C.c_int32, u32]),
             "ora_sampler_stream": (None, [C.c_int32, C.c_int32, u32, u64, u64, i, p]),
             "ora_pcg32_next": (u32, [p]), "ora_pcg32_new": (None, [u64, u64, p]),
+            "ora_set_transcendental_mode": (None, [i]), "ora_get_transcendental_mode": (i, []),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -67,6 +68,20 @@ def lib():
 
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class correctly_rounded:
+    """with oracle.correctly_rounded(): sin / cos / atan2 / atanh / cosh / exp of the per-sample path are evaluated in f64 and
+    rounded once (as the device kernels evaluate them) instead of by glibc's f32 routines (the faithful default)."""
+
+    def __enter__(self):
+        self._old = lib().ora_get_transcendental_mode()
+        lib().ora_set_transcendental_mode(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().ora_set_transcendental_mode(self._old)
+        return False
 
 
 class Scene:

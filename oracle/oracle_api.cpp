@@ -331,6 +331,10 @@ void ora_rgb_table_convert(const float* z_nodes, const float* coeffs, const floa
     }
 }
 
+// transcendental mode of the per-sample path (ref_core.h trans_mode): 0 faithful glibc f32, 1 f64-evaluated and rounded
+void ora_set_transcendental_mode(int mode) { trans_mode() = mode ? 1 : 0; }
+int ora_get_transcendental_mode() { return trans_mode(); }
+
 // ---- single-function probes used by the golden-vector tests -----------------------------------
 float ora_next_float_up(float v) { return next_float_up(v); }
 float ora_next_float_down(float v) { return next_float_down(v); }

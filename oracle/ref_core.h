@@ -70,6 +70,20 @@ static inline float clampf(float x, float lo, float hi) {                      /
 }
 static inline float safe_acos(float x) { return std::acos(clampf(x, -1.0f, 1.0f)); }
 
+// Transcendental functions of the per-sample path (sin, cos, atan2, atanh, cosh, exp).  Two modes:
+//   0  FAITHFUL (default): glibc's f32 routines - what Rust's std f32::sin etc. call on Linux.
+//   1  CORRECTLY ROUNDED: evaluated in f64 and rounded once to f32 - what the device kernels do (pm_shade.hpp cr_*), because
+//      ROCm's f32 routines differ from glibc's in the last ulp.  In this mode the oracle and the GPU run the same arithmetic
+//      (up to the ~2^-29 of inputs on which two f64 libms round differently), so samples compare bit for bit and a logic
+//      bug can no longer hide inside a "libm flipped a discrete outcome" tolerance.
+inline int& trans_mode() { static int mode = 0; return mode; }
+static inline float t_sin(float x) { return trans_mode() ? (float)std::sin((double)x) : std::sin(x); }
+static inline float t_cos(float x) { return trans_mode() ? (float)std::cos((double)x) : std::cos(x); }
+static inline float t_atan2(float y, float x) { return trans_mode() ? (float)std::atan2((double)y, (double)x) : std::atan2(y, x); }
+static inline float t_atanh(float x) { return trans_mode() ? (float)std::atanh((double)x) : std::atanh(x); }
+static inline float t_cosh(float x) { return trans_mode() ? (float)std::cosh((double)x) : std::cosh(x); }
+static inline float t_exp(float x) { return trans_mode() ? (float)std::exp((double)x) : std::exp(x); }
+
 // src/math.rs:78-87
 static inline float difference_of_products(float a, float b, float c, float d) {
     float cd = c * d;

@@ -69,7 +69,7 @@ static inline float blackbody(float lambda, float temp) {   // spectrum.rs:378-4
     float l = lambda * 1e-9f;
     float l5 = l * l * l * l * l;    // powi(5): llvm.powi expands by repeated squaring: ((l*l)*(l*l))*l
     l5 = ((l * l) * (l * l)) * l;
-    return (2.0f * H * C * C) / (l5 * (std::exp((H * C) / (l * KB * temp)) - 1.0f));
+    return (2.0f * H * C * C) / (l5 * (t_exp((H * C) / (l * KB * temp)) - 1.0f));
 }
 static inline float spectrum_at(const OSpectrum& s, float lambda) {
     switch (s.kind) {
@@ -115,13 +115,13 @@ static inline V3 sample_uniform_sphere(P2 u) {          // :260-266
     float z = 1.0f - 2.0f * u.x;
     float r = safe_sqrt(1.0f - z * z);
     float phi = 2.0f * PI_F * u.y;
-    return V3(r * std::cos(phi), r * std::sin(phi), z);
+    return V3(r * t_cos(phi), r * t_sin(phi), z);
 }
 static inline V3 sample_uniform_hemisphere(P2 u) {      // :270-276
     float z = u.x;
     float r = safe_sqrt(1.0f - z * z);
     float phi = 2.0f * PI_F * u.y;
-    return V3(r * std::cos(phi), r * std::sin(phi), z);
+    return V3(r * t_cos(phi), r * t_sin(phi), z);
 }
 static inline P2 sample_uniform_disk_concentric(P2 u) {  // :278-298
     P2 o{2.0f * u.x - 1.0f, 2.0f * u.y - 1.0f};
@@ -129,12 +129,12 @@ static inline P2 sample_uniform_disk_concentric(P2 u) {  // :278-298
     float r, theta;
     if (std::fabs(o.x) > std::fabs(o.y)) { r = o.x; theta = FRAC_PI_4 * (o.y / o.x); }
     else { r = o.y; theta = FRAC_PI_2 - FRAC_PI_4 * (o.x / o.y); }
-    return P2{std::cos(theta) * r, std::sin(theta) * r};
+    return P2{t_cos(theta) * r, t_sin(theta) * r};
 }
 static inline P2 sample_uniform_disk_polar(P2 u) {       // :300-305
     float r = std::sqrt(u.x);
     float theta = 2.0f * PI_F * u.y;
-    return P2{r * std::cos(theta), r * std::sin(theta)};
+    return P2{r * t_cos(theta), r * t_sin(theta)};
 }
 static inline V3 sample_cosine_hemisphere(P2 u) {        // :329-334
     P2 d = sample_uniform_disk_concentric(u);

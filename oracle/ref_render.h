@@ -158,13 +158,13 @@ static inline bool m4_inverse(const M4& M, M4* out) {
 // ------------------------------------------------------------------ wavelengths (spectrum.rs:73-91)
 static inline float visible_wavelengths_pdf(float lambda) {
     if (lambda >= 360.0f && lambda <= 830.0f) {
-        float ch = std::cosh(0.0072f * (lambda - 538.0f));
+        float ch = t_cosh(0.0072f * (lambda - 538.0f));
         return 0.003939804f / (ch * ch);
     }
     return 0.0f;
 }
 static inline float sample_visible_wavelengths(float u) {
-    return 538.0f - 138.88889f * std::atanh(0.85691062f - 1.827502f * u);
+    return 538.0f - 138.88889f * t_atanh(0.85691062f - 1.827502f * u);
 }
 
 }  // namespace ora

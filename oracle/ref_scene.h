@@ -86,7 +86,7 @@ static inline bool sphere_basic_intersect(const Sphere& s, V3 ro, V3 rd, float t
         V3 ph = om + th.midpoint() * dm;
         ph = ph * (s.radius / distance(ph, V3(0, 0, 0)));
         if (ph.x == 0.0f && ph.y == 0.0f) ph.x = 1e-5f * s.radius;
-        float f = std::atan2(ph.y, ph.x);
+        float f = t_atan2(ph.y, ph.x);
         if (f <= 0.0f) f += 2.0f * PI_F;
         *p = ph; *phi = f;
     };

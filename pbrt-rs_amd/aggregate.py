@@ -154,6 +154,12 @@ class GpuAggregate:
         return {"rays": c.rays, "nodes_visited": c.nodes_visited, "prims_tested": c.prims_tested,
                 "stack_overflows": c.stack_overflows, "exact_tests": c.exact_tests, "fallback_walks": c.fallback_walks}
 
+    def debug_uniforms(self, px, py, seed, sample_index, dimension, n):
+        """first n uniforms of the device's sample stream for (pixel, sample index, dimension) — test hook"""
+        out = np.zeros(n, np.float32)
+        self._check(self._lib.pm_debug_uniforms(self._h, px, py, seed, sample_index, dimension, n, out.ctypes.data))
+        return out
+
     def last_kernel_ms(self):
         ms = C.c_float()
         self._check(self._lib.pm_last_kernel_ms(self._h, C.byref(ms)))

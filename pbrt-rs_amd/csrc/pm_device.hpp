@@ -158,7 +158,7 @@ PMD void sphere_point_phi(f3 om, f3 dm, float tm, float radius, f3* p, float* ph
     f3 ph = om + dm * tm;
     ph = ph * (radius / len3(ph));
     if (ph.x == 0.0f && ph.y == 0.0f) ph.x = 1e-5f * radius;
-    float f = atan2f(ph.y, ph.x);
+    float f = (float)atan2((double)ph.y, (double)ph.x);     // f64, rounded once: see pm_shade.hpp on transcendentals
     if (f <= 0.0f) f += 2.0f * 3.14159265358979323846f;
     *p = ph; *phi = f;
 }

@@ -1061,6 +1061,29 @@ extern "C" int pm_debug_sample(pm_ctx* c, const PmRenderParams* p, int32_t px, i
     if (!out13) return fail(c, PM_ERR_INVALID, "pm_debug_sample: null out");
     return render_impl(c, p, true, px, py, s, out13);
 }
+// test hook: the first n uniforms of the sample stream of (pixel, sample index, dimension), drawn on the device
+__global__ void debug_uniforms_kernel(int px, int py, uint32_t seed, unsigned long long sample_index, unsigned long long dim, int n,
+                                      float* __restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Rng rng = rng_start(px, py, seed, sample_index, dim);
+    for (int i = 0; i < n; ++i) out[i] = rng_uniform(&rng);
+}
+extern "C" int pm_debug_uniforms(pm_ctx* c, int32_t px, int32_t py, uint32_t seed, uint64_t sample_index, uint64_t dimension,
+                                 int32_t n, float* out) {
+    if (!c || !out || n < 0) return fail(c, PM_ERR_INVALID, "pm_debug_uniforms: bad argument");
+    if (c->device < 0) return fail(c, PM_ERR_INVALID, "pm_debug_uniforms: host-only context");
+    if (n == 0) return PM_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    float* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, (size_t)n * sizeof(float)));
+    hipLaunchKernelGGL(debug_uniforms_kernel, dim3(1), dim3(64), 0, c->stream, px, py, seed, (unsigned long long)sample_index,
+                       (unsigned long long)dimension, n, d);
+    hipError_t e = hipMemcpyAsync(out, d, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, PM_ERR_HIP, std::string("pm_debug_uniforms: ") + hipGetErrorString(e));
+    return PM_OK;
+}
 extern "C" int pm_get_render_stats(pm_ctx* c, PmRenderStats* out) {
     if (!c || !out || !c->render) return fail(c, PM_ERR_INVALID, "pm_get_render_stats: nothing rendered");
     *out = c->render->stats;
