@@ -163,8 +163,24 @@ typedef struct PmMaterial {
 } PmMaterial;
 
 /* lights/{point,directional,infinite}.rs; `spectrum` is the light's DenselySampledSpectrum (471 floats) */
-enum { PM_LIGHT_POINT = 0, PM_LIGHT_DIRECTIONAL = 1, PM_LIGHT_UNIFORM_INFINITE = 2 };
-typedef struct PmLight { int32_t type; float scale; float render_from_light[16]; const float* spectrum; } PmLight;
+enum { PM_LIGHT_POINT = 0, PM_LIGHT_DIRECTIONAL = 1, PM_LIGHT_UNIFORM_INFINITE = 2,
+       /* EXTENSION (the reference has no area light: lights/base.rs:18-22, although GeometricPrimitive carries an `area_light`
+        * field, primitives/single.rs:13-19): a diffuse emitter on the patch / triangle `prim_id`, radiance scale * spectrum on the
+        * side its surface normal faces (both sides if two_sided).  Sampled through BilinearPatch::sample_with_context's
+        * area-sampling branch (shapes/bilinear_patch.rs:260-352; the spherical-rectangle branch is todo!() upstream); seen by
+        * rays through SurfaceInteraction::emitted_radiance (core/interaction.rs:179-184, simple_path.rs:156-158). */
+       PM_LIGHT_DIFFUSE_AREA = 3 };
+typedef struct PmLight {
+    int32_t type; float scale; float render_from_light[16]; const float* spectrum;
+    uint32_t prim_id; int32_t two_sided;      /* PM_LIGHT_DIFFUSE_AREA only */
+} PmLight;
+
+/* media/medium.rs:41-69 HomogeneousMedium::new(sigma_a, sigma_s, sigma_scale, emission = 0, g): the two coefficient spectra
+ * densely sampled (471 floats, 360..830 nm) and ALREADY multiplied by sigma_scale; Henyey-Greenstein asymmetry g
+ * (media/phase_function.rs:27-80).  EXTENSION: no reference integrator consumes a medium, and instead of MediumInterface
+ * (media/medium_interface.rs) the medium fills the axis-aligned box `bounds` (min xyz, max xyz, render space; +-INFINITY =
+ * all of space).  Only PM_INTEGRATOR_VOL_PATH looks at it. */
+typedef struct PmMedium { const float* sigma_a; const float* sigma_s; float g; float bounds[6]; } PmMedium;
 
 /* camera/perspective.rs:20-25 + camera/base.rs:260-327: the two matrices generate_ray uses */
 typedef struct PmCamera {
@@ -186,7 +202,13 @@ typedef struct PmFilm {
     const float* filter_vals;
 } PmFilm;
 
-enum { PM_INTEGRATOR_SIMPLE_PATH = 0, PM_INTEGRATOR_RANDOM_WALK = 1 };
+enum { PM_INTEGRATOR_SIMPLE_PATH = 0, PM_INTEGRATOR_RANDOM_WALK = 1,
+       /* EXTENSION (integrators/base.rs:26-30 has no volumetric integrator; scenes/test.pbrt asks for "volpath"):
+        * SimplePathIntegrator whose rays are first sampled for a real collision inside the medium of pm_set_medium
+        * (distance ~ sigma_t at the first wavelength; absorbed -> the path ends; scattered -> a path vertex with next-event
+        * estimation through the phase function and an HG-sampled continuation) and whose shadow rays are attenuated by the
+        * transmittance exp(-sigma_t d).  Without a medium it is SimplePath. */
+       PM_INTEGRATOR_VOL_PATH = 2 };
 typedef struct PmRenderParams {
     int32_t integrator, max_depth, sample_lights, sample_bsdf;
     int32_t spp;              /* sampler.samples_per_pixel() */
@@ -211,6 +233,7 @@ typedef struct PmRenderStats {
 int pm_set_materials(pm_ctx* ctx, const PmMaterial* mats, uint32_t n);
 int pm_set_prim_materials(pm_ctx* ctx, const uint32_t* material_id_per_prim, uint32_t n);
 int pm_set_lights(pm_ctx* ctx, const PmLight* lights, uint32_t n);
+int pm_set_medium(pm_ctx* ctx, const PmMedium* medium_or_null);   /* NULL removes the medium */
 int pm_set_camera(pm_ctx* ctx, const PmCamera* cam);
 int pm_set_film(pm_ctx* ctx, const PmFilm* film);           /* (re)allocates and clears the film */
 /* Integrate::render() restricted to a pixel/sample window; accumulates into the film in sample-index order.

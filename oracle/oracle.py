@@ -165,6 +165,7 @@ class Renderer:
         L.ora_renderer_scene_radius.restype = C.c_float
         L.ora_renderer_scene_radius.argtypes = [p]
         L.ora_renderer_sample.argtypes = [p, p, C.c_int, C.c_int, C.c_int, p]
+        L.ora_renderer_set_medium.argtypes = [p, p, p, C.c_float, p]
         self._l = L
         self._scene = scene
         pm = np.ascontiguousarray(prim_materials, dtype=np.uint32)
@@ -172,6 +173,12 @@ class Renderer:
                                                    C.addressof(lights), n_lights, C.addressof(camera), C.addressof(film)))
         b = film.pixel_bounds
         self.width, self.height = b[2] - b[0], b[3] - b[1]
+
+    def set_medium(self, sigma_a, sigma_s, g, bounds):
+        """HomogeneousMedium for the VOL_PATH integrator (tables already scaled); bounds = 6 floats"""
+        a, s = _f32(sigma_a), _f32(sigma_s)
+        b = _f32(bounds)
+        self._l.ora_renderer_set_medium(self._h, a.ctypes.data, s.ctypes.data, g, b.ctypes.data)
 
     def render(self, params, nthreads=8):
         ctr = np.zeros(4, np.uint64)

@@ -268,7 +268,7 @@ struct OraRenderer {
 OraRenderer* ora_renderer_create(OraScene* s, const OMaterial* mats, uint32_t n_mats, const uint32_t* prim_mat, uint32_t n_prims,
                                  const OLight* lights, uint32_t n_lights, const OCamera* cam, const OFilm* film) {
     OraRenderer* o = new OraRenderer();
-    o->tables.reserve(n_mats + n_lights + 8);
+    o->tables.reserve(n_mats + n_lights + 16);
     o->r.scene = &s->sc;
     o->r.materials.assign(mats, mats + n_mats);
     for (auto& m : o->r.materials) if (m.spec.table) m.spec.table = o->own(m.spec.table, 471);
@@ -283,6 +283,14 @@ OraRenderer* ora_renderer_create(OraScene* s, const OMaterial* mats, uint32_t n_
     return o;
 }
 void ora_renderer_destroy(OraRenderer* o) { delete o; }
+// HomogeneousMedium (media/medium.rs:49-68) for INTEGRATOR_VOL_PATH; null tables remove it
+void ora_renderer_set_medium(OraRenderer* o, const float* sigma_a471, const float* sigma_s471, float g, const float* bounds6) {
+    o->r.have_medium = sigma_a471 && sigma_s471;
+    if (!o->r.have_medium) return;
+    o->r.medium.sigma_a = o->own(sigma_a471, 471); o->r.medium.sigma_s = o->own(sigma_s471, 471);
+    o->r.medium.g = g;
+    for (int k = 0; k < 6; ++k) o->r.medium.bounds[k] = bounds6[k];
+}
 void ora_renderer_render(OraRenderer* o, const ORender* rp, int nthreads, uint64_t* counters4) {
     RenderCounters rc = o->r.render(*rp, nthreads);
     if (counters4) { counters4[0] = rc.samples; counters4[1] = rc.closest_rays; counters4[2] = rc.shadow_rays; counters4[3] = rc.bounces; }
@@ -329,6 +337,29 @@ void ora_rgb_table_convert(const float* z_nodes, const float* coeffs, const floa
         out3[c] = lerpf(lerpf(lerpf(co(0, 0, 0), co(1, 0, 0), dx), lerpf(co(0, 1, 0), co(1, 1, 0), dx), dy),
                         lerpf(lerpf(co(0, 0, 1), co(1, 0, 1), dx), lerpf(co(0, 1, 1), co(1, 1, 1), dx), dy), dz);
     }
+}
+
+// probes of the C5 extensions (media/phase_function.rs:57-80, shapes/bilinear_patch.rs:260-352)
+float ora_henyey_greenstein(float cos_theta, float g) { return henyey_greenstein(cos_theta, g); }
+void ora_sample_henyey_greenstein(const float* wo3, float g, const float* u2, float* wi3_pdf) {
+    float pdf;
+    V3 wi = sample_henyey_greenstein(V3(wo3[0], wo3[1], wo3[2]), g, P2{u2[0], u2[1]}, &pdf);
+    wi3_pdf[0] = wi.x; wi3_pdf[1] = wi.y; wi3_pdf[2] = wi.z; wi3_pdf[3] = pdf;
+}
+// BilinearPatch::sample_with_context from ref_p: out7 = point, normal, solid-angle pdf; returns 0 when there is no sample
+int ora_patch_sample_ctx(const float* p12, const float* ref_p3, const float* u2, float* out7) {
+    Patch p; auto P = [&](int k) { return V3(p12[3 * k], p12[3 * k + 1], p12[3 * k + 2]); };
+    p.p00 = P(0); p.p10 = P(1); p.p01 = P(2); p.p11 = P(3); p.flip_normal = false;
+    ShapeSample ss;
+    if (!patch_sample_ctx(p, V3(ref_p3[0], ref_p3[1], ref_p3[2]), P2{u2[0], u2[1]}, &ss)) return 0;
+    V3 m = ss.pi.midpoints();
+    out7[0] = m.x; out7[1] = m.y; out7[2] = m.z; out7[3] = ss.n.x; out7[4] = ss.n.y; out7[5] = ss.n.z; out7[6] = ss.pdf;
+    return 1;
+}
+int ora_patch_is_rectangle(const float* p12) {
+    Patch p; auto P = [&](int k) { return V3(p12[3 * k], p12[3 * k + 1], p12[3 * k + 2]); };
+    p.p00 = P(0); p.p10 = P(1); p.p01 = P(2); p.p11 = P(3);
+    return patch_is_rectangle(p) ? 1 : 0;
 }
 
 // transcendental mode of the per-sample path (ref_core.h trans_mode): 0 faithful glibc f32, 1 f64-evaluated and rounded

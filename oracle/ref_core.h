@@ -83,6 +83,7 @@ static inline float t_atan2(float y, float x) { return trans_mode() ? (float)std
 static inline float t_atanh(float x) { return trans_mode() ? (float)std::atanh((double)x) : std::atanh(x); }
 static inline float t_cosh(float x) { return trans_mode() ? (float)std::cosh((double)x) : std::cosh(x); }
 static inline float t_exp(float x) { return trans_mode() ? (float)std::exp((double)x) : std::exp(x); }
+static inline float t_log(float x) { return trans_mode() ? (float)std::log((double)x) : std::log(x); }
 
 // src/math.rs:78-87
 static inline float difference_of_products(float a, float b, float c, float d) {

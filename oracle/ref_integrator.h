@@ -89,8 +89,11 @@ static inline Spec4 spectrum_sample(const OSpectrum& s, const Wavelengths& w) {
 // ---- flattened scene description ----------------------------------------------------------------
 enum { MAT_DIFFUSE = 0, MAT_DIELECTRIC = 1 };
 struct OMaterial { int32_t type; OSpectrum spec; float u_rough, v_rough; int32_t remap_roughness; };
-enum { LIGHT_POINT = 0, LIGHT_DIRECTIONAL = 1, LIGHT_UNIFORM_INFINITE = 2 };
-struct OLight { int32_t type; float scale; float render_from_light[16]; const float* spectrum; };
+enum { LIGHT_POINT = 0, LIGHT_DIRECTIONAL = 1, LIGHT_UNIFORM_INFINITE = 2, LIGHT_DIFFUSE_AREA = 3 };
+struct OLight { int32_t type; float scale; float render_from_light[16]; const float* spectrum; uint32_t prim_id; int32_t two_sided; };
+// media/medium.rs:41-69 HomogeneousMedium: sigma_a / sigma_s densely sampled and already scaled by sigma_scale, HG asymmetry g;
+// bounds (extension, replaces MediumInterface): the medium fills this axis-aligned box of render space (+-inf = everywhere)
+struct OMedium { const float* sigma_a; const float* sigma_s; float g; float bounds[6]; };
 struct OCamera { float camera_from_raster[16]; float render_from_camera[16]; float lens_radius, focal_distance; };
 enum { FILTER_BOX = 0, FILTER_TRIANGLE = 1, FILTER_GAUSSIAN = 2 };
 struct OFilm {
@@ -101,7 +104,7 @@ struct OFilm {
     int32_t filter_kind; float filter_radius[2];
     int32_t filter_nx, filter_ny; const float* filter_vals;   // tabulated filter (Gaussian), row-major
 };
-enum { INTEGRATOR_SIMPLE_PATH = 0, INTEGRATOR_RANDOM_WALK = 1 };
+enum { INTEGRATOR_SIMPLE_PATH = 0, INTEGRATOR_RANDOM_WALK = 1, INTEGRATOR_VOL_PATH = 2 };
 struct ORender {
     int32_t integrator, max_depth, sample_lights, sample_bsdf;
     int32_t spp; uint32_t seed;
@@ -188,6 +191,90 @@ static inline float sample_tent(float u, float r) {
     float ur = rmin((up - sum) / w[off], ONE_MINUS_EPSILON);
     if (off == 0) return -r + r * sample_linear(ur, 0.0f, 1.0f);
     return r * sample_linear(ur, 1.0f, 0.0f);
+}
+
+// sampling/routines.rs:219-246.  B14 REPRODUCED: sample_bilinear passes (y, w0, w2) to a lerp whose signature is (a, b, t).
+static inline float bilinear_pdf(P2 p, const float w[4]) {
+    float w_sum = 0.0f; for (int i = 0; i < 4; ++i) w_sum += w[i];
+    if (p.x < 0.0f || p.x > 1.0f || p.y < 0.0f || p.y > 1.0f) return 0.0f;
+    if (w_sum == 0.0f) return 1.0f;
+    return 4.0f * ((1.0f - p.x) * (1.0f - p.y) * w[0] + p.x * (1.0f - p.y) * w[1] + p.y * (1.0f - p.x) * w[2] + p.x * p.y * w[3]) / w_sum;
+}
+static inline P2 sample_bilinear(P2 u, const float w[4]) {
+    float y = sample_linear(u.y, w[0] + w[1], w[2] + w[3]);
+    float x = sample_linear(u.x, lerpf(y, w[0], w[2]), lerpf(y, w[1], w[3]));
+    return P2{x, y};
+}
+static inline float sample_exponential(float u, float a) { return -t_log(1.0f - u) / a; }   // routines.rs:148-150
+
+// media/phase_function.rs:57-80
+static inline float henyey_greenstein(float cos_theta, float g) {
+    float denom = 1.0f + g * g + 2.0f * g * cos_theta;
+    return INV_4_PI * (1.0f - g * g) / (denom * safe_sqrt(denom));
+}
+static inline V3 sample_henyey_greenstein(V3 wo, float g, P2 u, float* pdf) {
+    float cos_theta;
+    if (std::fabs(g) < 1e-3f) cos_theta = 1.0f - 2.0f * u.x;
+    else {
+        float q = (1.0f - g * g) / (1.0f + g - 2.0f * g * u.x);
+        cos_theta = -1.0f / (2.0f * g) * (1.0f + g * g - q * q);       // powi(2) == x * x
+    }
+    float sin_theta = safe_sqrt(1.0f - cos_theta * cos_theta);
+    float phi = 2.0f * PI_F * u.y;
+    V3 x, y;                                                          // Frame::from_z(wo): (z, x, y) = wo.coordinate_system()
+    coordinate_system(wo, &x, &y);
+    float st = clampf(sin_theta, -1.0f, 1.0f), ct = clampf(cos_theta, -1.0f, 1.0f);     // spherical_direction, vec_math.rs:40-46
+    V3 l(st * t_cos(phi), st * t_sin(phi), ct);
+    *pdf = henyey_greenstein(cos_theta, g);
+    return l.x * x + l.y * y + l.z * wo;                              // Frame::from_local
+}
+
+// ---- shape sampling of bilinear patches (shapes/bilinear_patch.rs:256-353, 739-773) ----------------------------------
+static inline bool v3_eq(V3 a, V3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+static inline bool patch_is_rectangle(const Patch& p) {
+    if (v3_eq(p.p00, p.p01) || v3_eq(p.p01, p.p11) || v3_eq(p.p11, p.p10) || v3_eq(p.p10, p.p00)) return false;
+    V3 n = normalized(cross(p.p10 - p.p00, p.p01 - p.p00));
+    if (absdot(normalized(p.p11 - p.p00), n) > 1e-5f) return false;
+    V3 c = (p.p00 + p.p10 + p.p01 + p.p11) / 4.0f;
+    float d2[4] = {distance_squared(p.p00, c), distance_squared(p.p10, c), distance_squared(p.p01, c), distance_squared(p.p11, c)};
+    for (int i = 0; i < 4; ++i) if (std::fabs(d2[i] - d2[0]) / d2[0] > 1e-4f) return false;
+    return true;
+}
+struct ShapeSample { V3fi pi; V3 n; float pdf; };
+// BilinearPatch::sample (:260-318); no image distribution, no mesh uvs
+static inline bool patch_sample(const Patch& p, P2 u, ShapeSample* out) {
+    P2 uv; float pdf;
+    if (!patch_is_rectangle(p)) {
+        const float w[4] = {length(cross(p.p10 - p.p00, p.p01 - p.p00)), length(cross(p.p10 - p.p00, p.p11 - p.p10)),
+                            length(cross(p.p01 - p.p00, p.p11 - p.p01)), length(cross(p.p11 - p.p10, p.p11 - p.p01))};
+        uv = sample_bilinear(u, w); pdf = bilinear_pdf(uv, w);
+    } else { uv = u; pdf = 1.0f; }
+    V3 pu0 = vlerp(p.p00, p.p01, uv.y), pu1 = vlerp(p.p10, p.p11, uv.y);
+    V3 pt = vlerp(pu0, pu1, uv.x);
+    V3 dpdu = pu1 - pu0;
+    V3 dpdv = vlerp(p.p01, p.p11, uv.x) - vlerp(p.p00, p.p10, uv.x);
+    if (length_squared(dpdu) == 0.0f || length_squared(dpdv) == 0.0f) return false;
+    V3 n = normalized(cross(dpdu, dpdv));
+    if (p.has_normals) {
+        V3 ns = vlerp(vlerp(p.n00, p.n01, uv.y), vlerp(p.n10, p.n11, uv.y), uv.x);
+        n = face_forward(n, ns);
+    } else if (p.flip_normal) n = -n;
+    V3 pabs = vabs(p.p00) + vabs(p.p01) + vabs(p.p10) + vabs(p.p11);
+    out->pi = V3fi::with_err(pt, gamma_n(6) * pabs);
+    out->n = n;
+    out->pdf = pdf / length(cross(dpdu, dpdv));
+    return true;
+}
+// BilinearPatch::sample_with_context (:320-352), the area-sampling branch.  The spherical-rectangle branch of rectangles ends
+// in sample_spherical_rectangle, which is todo!() upstream (sampling/routines.rs:307-327): every patch takes this branch.
+static inline bool patch_sample_ctx(const Patch& p, V3 ref_p, P2 u, ShapeSample* out) {
+    if (!patch_sample(p, u, out)) return false;
+    V3 wi = out->pi.midpoints() - ref_p;
+    if (length_squared(wi) == 0.0f) return false;
+    wi = normalized(wi);
+    out->pdf /= absdot(out->n, -wi) / distance_squared(ref_p, out->pi.midpoints());
+    if (std::isinf(out->pdf)) return false;
+    return true;
 }
 
 struct FilterSamplerO {                                  // imaging/filter.rs:177-225 + routines.rs:436-503
@@ -463,6 +550,9 @@ struct Renderer {
     std::vector<OMaterial> materials;
     std::vector<OLight> lights;
     std::vector<int> infinite_lights;
+    std::vector<int> prim_area_light;         // by prim id: index of the DiffuseAreaLight on that primitive, or -1
+    std::vector<int> prim_patch;              // by prim id: index into scene->patches (-1 for spheres)
+    bool have_medium = false; OMedium medium{};
     OCamera cam; OFilm film; FilterSamplerO fsampler;
     V3 scene_center; float scene_radius;
     std::vector<double> pixels;               // 4 doubles per pixel: rgb_sum[3], weight_sum (film.rs:302-307)
@@ -472,6 +562,10 @@ struct Renderer {
         b3_bounding_sphere(scene->bounds(), &scene_center, &scene_radius);   // integrators/base.rs:54-70
         infinite_lights.clear();
         for (size_t i = 0; i < lights.size(); ++i) if (lights[i].type == LIGHT_UNIFORM_INFINITE) infinite_lights.push_back((int)i);
+        prim_area_light.assign(prim_material.size(), -1); prim_patch.assign(prim_material.size(), -1);
+        for (const Prim& p : scene->prims) if (p.type != PRIM_SPHERE && p.id < prim_patch.size()) prim_patch[p.id] = (int)p.index;
+        for (size_t i = 0; i < lights.size(); ++i)          // GeometricPrimitive.area_light (primitives/single.rs:13-19)
+            if (lights[i].type == LIGHT_DIFFUSE_AREA && lights[i].prim_id < prim_area_light.size()) prim_area_light[lights[i].prim_id] = (int)i;
         int w = film.bounds[2] - film.bounds[0], h = film.bounds[3] - film.bounds[1];
         pixels.assign((size_t)w * h * 4, 0.0);
     }
@@ -480,6 +574,72 @@ struct Renderer {
     Spec4 light_L(const OLight& l, const Wavelengths& w) const {   // scale * spectrum.sample(lambda)
         Spec4 r; for (int i = 0; i < NSP; ++i) r.v[i] = dense_at(l.spectrum, w.lambda[i]) * l.scale; return r;
     }
+    // DiffuseAreaLight::L (extension: the reference has no area light, lights/base.rs:18-22; pbrt-v4 semantics): one-sided
+    // lights emit on the side their surface normal points to
+    Spec4 area_L(const OLight& l, V3 n, V3 w, const Wavelengths& wl) const {
+        if (!l.two_sided && dot(n, w) < 0.0f) return spec_const(0.0f);
+        return light_L(l, wl);
+    }
+    // homogeneous medium (media/medium.rs:78-96): sigma_a, sigma_s at the wavelengths; sigma_maj = sigma_a + sigma_s
+    void medium_sigmas(const Wavelengths& w, Spec4* sa, Spec4* ss, Spec4* st) const {
+        for (int i = 0; i < NSP; ++i) {
+            sa->v[i] = dense_at(medium.sigma_a, w.lambda[i]); ss->v[i] = dense_at(medium.sigma_s, w.lambda[i]);
+            st->v[i] = sa->v[i] + ss->v[i];
+        }
+    }
+    // the part [t0, t1] of the ray's [0, t_max] that lies inside the medium's bounds (slab clip); false if empty
+    bool medium_segment(V3 ro, V3 rd, float t_max, float* t0o, float* t1o) const {
+        float t0 = 0.0f, t1 = t_max;
+        for (int a = 0; a < 3; ++a) {
+            float inv = 1.0f / rd[a];
+            float tn = (medium.bounds[a] - ro[a]) * inv, tf = (medium.bounds[3 + a] - ro[a]) * inv;
+            if (tn > tf) { float x = tn; tn = tf; tf = x; }
+            if (tn > t0) t0 = tn;
+            if (tf < t1) t1 = tf;
+        }
+        if (!(t0 < t1)) return false;
+        *t0o = t0; *t1o = t1;
+        return true;
+    }
+    // transmittance of the shadow segment o + t * dir, t in [0, t_max]: exp(-sigma_t * length inside the medium)
+    Spec4 shadow_tr(V3 o, V3 dir, float t_max, const Wavelengths& w) const {
+        Spec4 tr = spec_const(1.0f);
+        float t0, t1;
+        if (!have_medium || !medium_segment(o, dir, t_max, &t0, &t1)) return tr;
+        Spec4 sa, ss, st; medium_sigmas(w, &sa, &ss, &st);
+        float seg = (t1 - t0) * length(dir);
+        for (int i = 0; i < NSP; ++i) tr.v[i] = t_exp(-st.v[i] * seg);
+        return tr;
+    }
+    // Light::sample_li for every light type.  ref_p: the receiving point; returns false when the sample carries nothing.
+    bool sample_light(const OLight& lt, V3 ref_p, P2 u2, const Wavelengths& w, Spec4* Ls, V3* wi, float* pdf, V3* p_light) const {
+        if (lt.type == LIGHT_UNIFORM_INFINITE) {
+            *wi = sample_uniform_sphere(u2); *pdf = INV_4_PI; *Ls = light_L(lt, w);
+            *p_light = ref_p + *wi * (2.0f * scene_radius);
+        } else if (lt.type == LIGHT_DIRECTIONAL) {
+            *wi = normalized(xf_vec(m4(lt.render_from_light), V3(0, 0, 1))); *pdf = 1.0f; *Ls = light_L(lt, w);
+            *p_light = ref_p + *wi * (2.0f * scene_radius);
+        } else if (lt.type == LIGHT_POINT) {
+            V3 p = xf_point(m4(lt.render_from_light), V3(0, 0, 0));
+            *wi = normalized(p - ref_p); *pdf = 1.0f;
+            *Ls = light_L(lt, w);
+            float d2 = distance_squared(p, ref_p);
+            for (int i = 0; i < NSP; ++i) Ls->v[i] /= d2;
+            *p_light = p;
+        } else {      // DiffuseAreaLight::sample_li over BilinearPatch::sample_with_context
+            int pi = lt.prim_id < prim_patch.size() ? prim_patch[lt.prim_id] : -1;
+            if (pi < 0) return false;
+            ShapeSample ss;
+            if (!patch_sample_ctx(scene->patches[pi], ref_p, u2, &ss)) return false;
+            V3 pl = ss.pi.midpoints();
+            if (ss.pdf == 0.0f || length_squared(pl - ref_p) == 0.0f) return false;
+            *wi = normalized(pl - ref_p);
+            *Ls = area_L(lt, ss.n, -*wi, w);
+            *pdf = ss.pdf; *p_light = pl;
+        }
+        return true;
+    }
+
     SurfInt make_interaction(const Hit& h) const {
         const Prim& p = scene->prims[h.prim_slot];
         return p.type == PRIM_SPHERE ? sphere_interaction(scene->spheres[p.index], h) : patch_interaction(scene->patches[p.index], h);
@@ -535,24 +695,85 @@ struct Renderer {
         return !scene->intersect_p(o, dir, 1.0f - SHADOW_EPSILON);
     }
 
-    Spec4 li_simple_path(V3 ro, V3 rd, Wavelengths* w, Pcg32* rng, const ORender& rp, RenderCounters* rc) const {
+    // SimplePathIntegrator::incident_radiance (simple_path.rs:105-269).  vol: the medium-aware variant (INTEGRATOR_VOL_PATH, an
+    // extension - the reference has no volumetric integrator): before the surface is considered, the part of the ray inside the
+    // homogeneous medium is sampled for a real collision (distance ~ sigma_t[lambda_0], no null collisions since sigma_maj ==
+    // sigma_t): absorbed -> the path ends; scattered -> a path vertex with next-event estimation through the phase function and a
+    // Henyey-Greenstein sampled continuation.  Shadow rays are attenuated by the closed-form transmittance.
+    Spec4 li_simple_path(V3 ro, V3 rd, Wavelengths* w, Pcg32* rng, const ORender& rp, RenderCounters* rc, bool vol = false) const {
         Spec4 L = spec_const(0.0f), beta = spec_const(1.0f);
         bool specular_bounce = true;
         int depth = 0;
+        const bool use_medium = vol && have_medium;
         while (!spec_all_zero(beta)) {
             Hit h;
             rc->closest_rays++;
             bool hit = scene->intersect(ro, rd, std::numeric_limits<float>::infinity(), &h);
+            if (use_medium) {
+                float t0, t1;
+                if (medium_segment(ro, rd, hit ? h.t : std::numeric_limits<float>::infinity(), &t0, &t1)) {
+                    float dlen = length(rd), seg = (t1 - t0) * dlen;
+                    float u = rng->uniform_float(), um = rng->uniform_float();
+                    Spec4 sa, ss, st; medium_sigmas(*w, &sa, &ss, &st);
+                    float s = st.v[0] > 0.0f ? sample_exponential(u, st.v[0]) : std::numeric_limits<float>::infinity();
+                    if (s < seg) {
+                        if (um < sa.v[0] / st.v[0]) break;                       // absorbed (the medium does not emit)
+                        float T0 = t_exp(-st.v[0] * s);
+                        for (int i = 0; i < NSP; ++i) beta.v[i] *= t_exp(-st.v[i] * s) * ss.v[i] / (T0 * ss.v[0]);
+                        if (depth == rp.max_depth) break;
+                        depth++;
+                        rc->bounces++;
+                        V3 p = ro + rd * (t0 + s / dlen);
+                        V3 wo = -rd / dlen;
+                        if (rp.sample_lights) {
+                            float ul = rng->uniform_float();
+                            if (!lights.empty()) {
+                                size_t nl = lights.size();
+                                float fi = ul * (float)nl;
+                                size_t idx = fi > 0.0f ? (size_t)fi : 0; if (idx > nl - 1) idx = nl - 1;
+                                float prob = 1.0f / (float)nl;
+                                P2 u2; u2.x = rng->uniform_float(); u2.y = rng->uniform_float();
+                                Spec4 Ls; V3 wi, p_light; float pdf;
+                                if (sample_light(lights[idx], p, u2, *w, &Ls, &wi, &pdf, &p_light) && !spec_all_zero(Ls) && pdf > 0.0f) {
+                                    float f = henyey_greenstein(dot(wo, wi), medium.g);
+                                    if (f != 0.0f) {
+                                        V3 dir = p_light - p;
+                                        rc->shadow_rays++;
+                                        if (!scene->intersect_p(p, dir, 1.0f - SHADOW_EPSILON)) {
+                                            Spec4 tr = shadow_tr(p, dir, 1.0f - SHADOW_EPSILON, *w);
+                                            float den = prob * pdf;
+                                            for (int i = 0; i < NSP; ++i) L.v[i] += beta.v[i] * f * Ls.v[i] * tr.v[i] / den;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        P2 u2; u2.x = rng->uniform_float(); u2.y = rng->uniform_float();
+                        float ppdf;
+                        V3 wi = sample_henyey_greenstein(wo, medium.g, u2, &ppdf);      // value == pdf: beta is unchanged
+                        if (ppdf == 0.0f) break;
+                        specular_bounce = false;
+                        ro = p; rd = wi;
+                        continue;
+                    }
+                    float Tm0 = t_exp(-st.v[0] * seg);                           // no collision: T_maj / pdf of passing through
+                    for (int i = 0; i < NSP; ++i) beta.v[i] *= t_exp(-st.v[i] * seg) / Tm0;
+                }
+            }
             if (!hit) {
                 if (!rp.sample_lights || specular_bounce)
                     for (int li : infinite_lights) { Spec4 le = light_L(lights[li], *w); for (int i = 0; i < NSP; ++i) L.v[i] += beta.v[i] * le.v[i]; }
                 break;
             }
-            // emitted_radiance: no area lights exist (lights/base.rs:18-22); the reference adds beta * 0 here
+            SurfInt si = make_interaction(h);
+            // emitted_radiance (simple_path.rs:156-158, interaction.rs:179-184): only primitives that carry an area light emit
+            if ((!rp.sample_lights || specular_bounce) && prim_area_light[si.prim_id] >= 0) {
+                Spec4 le = area_L(lights[prim_area_light[si.prim_id]], si.n, -rd, *w);
+                for (int i = 0; i < NSP; ++i) L.v[i] += beta.v[i] * le.v[i];
+            }
             if (depth == rp.max_depth) break;
             depth++;
             rc->bounces++;
-            SurfInt si = make_interaction(h);
             BSDF bsdf = make_bsdf(si, w);
             V3 wo = -rd;
             if (rp.sample_lights) {
@@ -563,30 +784,20 @@ struct Renderer {
                     size_t idx = fi > 0.0f ? (size_t)fi : 0; if (idx > nl - 1) idx = nl - 1;
                     float prob = 1.0f / (float)nl;
                     P2 u2; u2.x = rng->uniform_float(); u2.y = rng->uniform_float();
-                    const OLight& lt = lights[idx];
                     Spec4 Ls; V3 wi, p_light; float pdf;
                     V3 pm = si.pi.midpoints();
-                    if (lt.type == LIGHT_UNIFORM_INFINITE) {
-                        wi = sample_uniform_sphere(u2); pdf = INV_4_PI; Ls = light_L(lt, *w);
-                        p_light = pm + wi * (2.0f * scene_radius);
-                    } else if (lt.type == LIGHT_DIRECTIONAL) {
-                        wi = normalized(xf_vec(m4(lt.render_from_light), V3(0, 0, 1))); pdf = 1.0f; Ls = light_L(lt, *w);
-                        p_light = pm + wi * (2.0f * scene_radius);
-                    } else {
-                        V3 p = xf_point(m4(lt.render_from_light), V3(0, 0, 0));
-                        wi = normalized(p - pm); pdf = 1.0f;
-                        Ls = light_L(lt, *w);
-                        float d2 = distance_squared(p, pm);
-                        for (int i = 0; i < NSP; ++i) Ls.v[i] /= d2;
-                        p_light = p;
-                    }
-                    if (!spec_all_zero(Ls) && pdf > 0.0f) {
+                    if (sample_light(lights[idx], pm, u2, *w, &Ls, &wi, &pdf, &p_light) && !spec_all_zero(Ls) && pdf > 0.0f) {
                         Spec4 f = bsdf.eval(wo, wi);
                         float ad = absdot(wi, si.ns);
                         for (int i = 0; i < NSP; ++i) f.v[i] *= ad;
                         if (!spec_all_zero(f) && unoccluded(si, p_light, rc)) {
                             float den = prob * pdf;
-                            for (int i = 0; i < NSP; ++i) L.v[i] += beta.v[i] * f.v[i] * Ls.v[i] / den;
+                            if (use_medium) {
+                                V3 dir = p_light - pm;
+                                Spec4 tr = shadow_tr(offset_ray_origin(si.pi, si.n, dir), dir, 1.0f - SHADOW_EPSILON, *w);
+                                for (int i = 0; i < NSP; ++i) L.v[i] += beta.v[i] * f.v[i] * Ls.v[i] * tr.v[i] / den;
+                            } else
+                                for (int i = 0; i < NSP; ++i) L.v[i] += beta.v[i] * f.v[i] * Ls.v[i] / den;
                         }
                     }
                 }
@@ -682,8 +893,8 @@ struct Renderer {
         P2 p_lens; p_lens.x = rng.uniform_float(); p_lens.y = rng.uniform_float();
         V3 ro, rd;
         generate_ray(p_film, p_lens, &ro, &rd);
-        Spec4 L = rp.integrator == INTEGRATOR_SIMPLE_PATH ? li_simple_path(ro, rd, &w, &rng, rp, rc)
-                                                          : li_random_walk(ro, rd, &w, &rng, rp, 0, rc);
+        Spec4 L = rp.integrator == INTEGRATOR_RANDOM_WALK ? li_random_walk(ro, rd, &w, &rng, rp, 0, rc)
+                                                          : li_simple_path(ro, rd, &w, &rng, rp, rc, rp.integrator == INTEGRATOR_VOL_PATH);
         for (int i = 0; i < NSP; ++i) L.v[i] = L.v[i] * 1.0f;   // * camera_ray.weight
         rc->samples++;
         if (L_out) { *L_out = L; *w_out = w; *fw_out = fweight; }

@@ -52,7 +52,12 @@ class PmMaterial(C.Structure):
 
 class PmLight(C.Structure):
     _fields_ = [("type", C.c_int32), ("scale", C.c_float), ("render_from_light", C.c_float * 16),
-                ("spectrum", C.POINTER(C.c_float))]
+                ("spectrum", C.POINTER(C.c_float)), ("prim_id", C.c_uint32), ("two_sided", C.c_int32)]
+
+
+class PmMedium(C.Structure):
+    _fields_ = [("sigma_a", C.POINTER(C.c_float)), ("sigma_s", C.POINTER(C.c_float)), ("g", C.c_float),
+                ("bounds", C.c_float * 6)]
 
 
 class PmCamera(C.Structure):
@@ -85,9 +90,9 @@ class PmRenderStats(C.Structure):
 
 PM_SPEC_CONSTANT, PM_SPEC_DENSE, PM_SPEC_RGB_ALBEDO, PM_SPEC_RGB_UNBOUNDED, PM_SPEC_RGB_ILLUMINANT, PM_SPEC_BLACKBODY = range(6)
 PM_MAT_DIFFUSE, PM_MAT_DIELECTRIC = 0, 1
-PM_LIGHT_POINT, PM_LIGHT_DIRECTIONAL, PM_LIGHT_UNIFORM_INFINITE = 0, 1, 2
+PM_LIGHT_POINT, PM_LIGHT_DIRECTIONAL, PM_LIGHT_UNIFORM_INFINITE, PM_LIGHT_DIFFUSE_AREA = 0, 1, 2, 3
 PM_FILTER_BOX, PM_FILTER_TRIANGLE, PM_FILTER_GAUSSIAN = 0, 1, 2
-PM_INTEGRATOR_SIMPLE_PATH, PM_INTEGRATOR_RANDOM_WALK = 0, 1
+PM_INTEGRATOR_SIMPLE_PATH, PM_INTEGRATOR_RANDOM_WALK, PM_INTEGRATOR_VOL_PATH = 0, 1, 2
 
 # every symbol include/pbrt_mi355.h and include/pbrt_mi355_host.h declare: name -> (restype, argtypes)
 _P = C.c_void_p
@@ -112,6 +117,7 @@ SYMBOLS = {
     "pm_set_materials": (C.c_int, [_P, C.POINTER(PmMaterial), C.c_uint32]),
     "pm_set_prim_materials": (C.c_int, [_P, _P, C.c_uint32]),
     "pm_set_lights": (C.c_int, [_P, C.POINTER(PmLight), C.c_uint32]),
+    "pm_set_medium": (C.c_int, [_P, C.POINTER(PmMedium)]),
     "pm_set_camera": (C.c_int, [_P, C.POINTER(PmCamera)]),
     "pm_set_film": (C.c_int, [_P, C.POINTER(PmFilm)]),
     "pm_render": (C.c_int, [_P, C.POINTER(PmRenderParams)]),

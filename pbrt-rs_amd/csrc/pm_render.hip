@@ -53,6 +53,7 @@ struct SceneArrays {
     const DShadePatch* patches; const DShadeSphere* spheres;
     const uint32_t* prim_material; const DMaterial* materials; const DLight* lights; const int* infinite;
     const float* pool;
+    const int* prim_light;           // prim id -> index of the DiffuseAreaLight on it, or -1 (null: the scene has no area light)
 };
 
 __device__ __forceinline__ bool slot_pixel(const RenderConst& rc, uint32_t slot, int* px, int* py, int* s) {
@@ -346,6 +347,46 @@ __device__ __forceinline__ Bsdf make_bsdf(const SceneArrays& sc, const PathArray
     return bsdf;
 }
 
+// Light::sample_li of every light type for the receiving point pm (lights/{point,directional,infinite}.rs; DiffuseAreaLight
+// over BilinearPatch::sample_with_context is an extension, EXT kernels only).  false: the sample carries nothing.
+template <bool EXT>
+__device__ __forceinline__ bool sample_light(const RenderConst& rc, const SceneArrays& sc, const DLight& lt, f3 pm, f2 u2,
+                                             const float* lam, Spec4* Ls, f3* wi, float* lpdf, f3* p_light) {
+    *Ls = light_L(sc, lt, lam);
+    if (lt.type == PM_LIGHT_UNIFORM_INFINITE) {
+        *wi = sample_uniform_sphere(u2); *lpdf = PM_INV_4PI;
+        *p_light = pm + *wi * (2.0f * rc.scene_radius);
+    } else if (lt.type == PM_LIGHT_DIRECTIONAL) {
+        *wi = norm3(mk3(0.0f * lt.m[0] + 0.0f * lt.m[1] + 1.0f * lt.m[2], 0.0f * lt.m[4] + 0.0f * lt.m[5] + 1.0f * lt.m[6],
+                        0.0f * lt.m[8] + 0.0f * lt.m[9] + 1.0f * lt.m[10]));
+        *lpdf = 1.0f;
+        *p_light = pm + *wi * (2.0f * rc.scene_radius);
+    } else if (!EXT || lt.type == PM_LIGHT_POINT) {
+        const f3 p = mk3(0.0f * lt.m[0] + 0.0f * lt.m[1] + 0.0f * lt.m[2] + lt.m[3], 0.0f * lt.m[4] + 0.0f * lt.m[5] + 0.0f * lt.m[6] + lt.m[7],
+                         0.0f * lt.m[8] + 0.0f * lt.m[9] + 0.0f * lt.m[10] + lt.m[11]);
+        const f3 dv = p - pm;
+        *wi = norm3(dv); *lpdf = 1.0f;
+        const float d2 = dot3(dv, dv);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Ls->v[c] /= d2;
+        *p_light = p;
+    } else {
+        ShapeSample ss;
+        const uint32_t ref = sc.prim_ref[lt.prim_id];
+        if (!patch_sample_ctx(sc.patches[ref & 0x3FFFFFFFu], sc.pool, pm, u2, &ss)) return false;
+        const f3 dv = ss.p - pm;
+        if (ss.pdf == 0.0f || dot3(dv, dv) == 0.0f) return false;
+        *wi = norm3(dv);
+        if (!lt.two_sided && dot3(ss.n, -*wi) < 0.0f) *Ls = spec_c(0.0f);
+        *lpdf = ss.pdf; *p_light = ss.p;
+    }
+    return true;
+}
+
+// EXT: the scene holds area lights and / or the integrator is PM_INTEGRATOR_VOL_PATH with a medium set.  That code (emission on
+// a hit, shape sampling, the medium event as a third outcome beside "surface" and "escaped") is compiled only into the EXT
+// variant: it costs registers, and the plain variant is the hot kernel of the C2 / C4 frames.
+template <bool EXT>
 __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ qin,
                                                    const uint32_t* __restrict__ count_in, uint32_t* __restrict__ qout,
                                                    uint32_t* __restrict__ count_out, uint32_t* __restrict__ shadow_count) {
@@ -369,7 +410,93 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
         bool specular = ((misc.x >> 8) & 1u) != 0u;
         const float4 rd4 = nt_load(pa.ray_d + slot);
         const f3 rd = mk3(rd4.x, rd4.y, rd4.z);
-        if (prim_id == 0xFFFFFFFFu) {
+        Rng rng; rng.state = 0ull; rng.inc = 0ull;
+        bool rng_dirty = false;
+        if (EXT) {
+            const uint4 r4 = pa.rng[slot];
+            rng.state = ((unsigned long long)r4.y << 32) | r4.x; rng.inc = ((unsigned long long)r4.w << 32) | r4.z;
+        }
+        // ---- medium event (EXT): a real collision inside the homogeneous medium before the surface is reached?
+        bool surface = true;                // false: the path ended or scattered in the medium
+        bool use_medium = false;
+        float sig_t[4] = {0.f, 0.f, 0.f, 0.f};
+        if (EXT && rc.medium_on) {
+            use_medium = true;
+            const float4 ro4 = pa.ray_o[slot];
+            const f3 ro = mk3(ro4.x, ro4.y, ro4.z);
+            float sig_a[4], sig_s[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                sig_a[c] = dense_at(sc.pool, rc.med_sigma_a, lam[c]); sig_s[c] = dense_at(sc.pool, rc.med_sigma_s, lam[c]);
+                sig_t[c] = sig_a[c] + sig_s[c];
+            }
+            float t0, t1;
+            if (medium_segment(rc.med_bounds, ro, rd, prim_id == 0xFFFFFFFFu ? INFINITY : hv.y, &t0, &t1)) {
+                const float dlen = len3(rd), seg = (t1 - t0) * dlen;
+                const float u = rng_uniform(&rng), um = rng_uniform(&rng);
+                rng_dirty = true;
+                const float s = sig_t[0] > 0.0f ? -cr_log(1.0f - u) / sig_t[0] : INFINITY;
+                if (s < seg) {
+                    surface = false;
+                    if (!(um < sig_a[0] / sig_t[0])) {          // scattered (absorbed otherwise: the path ends here)
+                        const float T0 = cr_exp(-sig_t[0] * s);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) beta[c] *= cr_exp(-sig_t[c] * s) * sig_s[c] / (T0 * sig_s[0]);
+                        if (depth != rc.max_depth) {
+                            depth++;
+                            const f3 p = ro + rd * (t0 + s / dlen);
+                            const f3 wo = (-rd) / dlen;
+                            if (rc.sample_lights) {
+                                const float ul = rng_uniform(&rng);
+                                if (rc.n_lights > 0) {
+                                    const float fi = ul * (float)rc.n_lights;
+                                    int idx = fi > 0.0f ? (int)fminf(fi, 2147483520.0f) : 0;
+                                    if (idx > rc.n_lights - 1) idx = rc.n_lights - 1;
+                                    const float prob = 1.0f / (float)rc.n_lights;
+                                    f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
+                                    Spec4 Ls; f3 wi, p_light; float lpdf;
+                                    if (sample_light<EXT>(rc, sc, sc.lights[idx], p, u2, lam, &Ls, &wi, &lpdf, &p_light) && !spec_zero(Ls) && lpdf > 0.0f) {
+                                        const float f = henyey_greenstein(dot3(wo, wi), rc.med_g);
+                                        if (f != 0.0f) {
+                                            const f3 dir = p_light - p;
+                                            const float den = prob * lpdf;
+                                            float tr[4] = {1.f, 1.f, 1.f, 1.f};
+                                            float s0, s1;
+                                            if (medium_segment(rc.med_bounds, p, dir, 1.0f - 0.0001f, &s0, &s1)) {
+                                                const float sl = (s1 - s0) * len3(dir);
+#pragma unroll
+                                                for (int c = 0; c < 4; ++c) tr[c] = cr_exp(-sig_t[c] * sl);
+                                            }
+                                            nt_store(pa.sh_o + slot, make_float4(p.x, p.y, p.z, 1.0f - 0.0001f));
+                                            nt_store(pa.sh_d + slot, make_float4(dir.x, dir.y, dir.z, 0.f));
+                                            nt_store(pa.sh_L + slot, make_float4(beta[0] * f * Ls.v[0] * tr[0] / den, beta[1] * f * Ls.v[1] * tr[1] / den,
+                                                                                 beta[2] * f * Ls.v[2] * tr[2] / den, beta[3] * f * Ls.v[3] * tr[3] / den));
+                                            want_shadow = true;
+                                        }
+                                    }
+                                }
+                            }
+                            f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
+                            float ppdf;
+                            const f3 wi = sample_henyey_greenstein(wo, rc.med_g, u2, &ppdf);
+                            if (ppdf != 0.0f && !(beta[0] == 0.0f && beta[1] == 0.0f && beta[2] == 0.0f && beta[3] == 0.0f)) {
+                                nt_store(pa.ray_o + slot, make_float4(p.x, p.y, p.z, 0.f));
+                                nt_store(pa.ray_d + slot, make_float4(wi.x, wi.y, wi.z, 0.f));
+                                nt_store(pa.beta + slot, make_float4(beta[0], beta[1], beta[2], beta[3]));
+                                nt_store(pa.misc + slot, make_uint2((uint32_t)depth, misc.y));      // specular_bounce = false
+                                cont = true;
+                            }
+                        }
+                    }
+                } else {
+                    const float Tm0 = cr_exp(-sig_t[0] * seg);       // passed through: T_maj over the pdf of doing so
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) beta[c] *= cr_exp(-sig_t[c] * seg) / Tm0;
+                }
+            }
+        }
+        if (!surface) {
+        } else if (prim_id == 0xFFFFFFFFu) {
             if (!rc.sample_lights || specular) {
                 const float4 L4 = pa.L[slot];           // only escaped rays touch L here (hits: the shadow kernel adds NEE)
                 float L[4] = {L4.x, L4.y, L4.z, L4.w};
@@ -380,8 +507,7 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                 }
                 pa.L[slot] = make_float4(L[0], L[1], L[2], L[3]);
             }
-        } else if (depth != rc.max_depth) {
-            depth++;
+        } else if (EXT || depth != rc.max_depth) {
             // ---- interaction
             const uint32_t ref = sc.prim_ref[prim_id];
             SurfInt si;
@@ -389,10 +515,27 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                 const float4 ro4 = pa.ray_o[slot];      // only the sphere's interaction needs the ray origin
                 si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], mk3(ro4.x, ro4.y, ro4.z), rd, hv.y);
             } else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
+            // ---- emitted radiance of an area light on this primitive (simple_path.rs:156-158; EXT only)
+            if (EXT && sc.prim_light && (!rc.sample_lights || specular)) {
+                const int li = sc.prim_light[prim_id];
+                if (li >= 0) {
+                    const DLight lt = sc.lights[li];
+                    if (lt.two_sided || !(dot3(si.n, -rd) < 0.0f)) {
+                        const Spec4 le = light_L(sc, lt, lam);
+                        const float4 L4 = pa.L[slot];
+                        pa.L[slot] = make_float4(L4.x + beta[0] * le.v[0], L4.y + beta[1] * le.v[1], L4.z + beta[2] * le.v[2], L4.w + beta[3] * le.v[3]);
+                    }
+                }
+            }
+            if (depth != rc.max_depth) {
+            depth++;
             Bsdf bsdf = make_bsdf(sc, pa, si, prim_id, lam, slot);
             const f3 wo = -rd;
-            const uint4 r4 = pa.rng[slot];
-            Rng rng; rng.state = ((unsigned long long)r4.y << 32) | r4.x; rng.inc = ((unsigned long long)r4.w << 32) | r4.z;
+            if (!EXT) {
+                const uint4 r4 = pa.rng[slot];
+                rng.state = ((unsigned long long)r4.y << 32) | r4.x; rng.inc = ((unsigned long long)r4.w << 32) | r4.z;
+            }
+            rng_dirty = true;
             // ---- next-event estimation (simple_path.rs:182-213)
             if (rc.sample_lights) {
                 const float ul = rng_uniform(&rng);
@@ -402,29 +545,9 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                     if (idx > rc.n_lights - 1) idx = rc.n_lights - 1;
                     const float prob = 1.0f / (float)rc.n_lights;
                     f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
-                    const DLight lt = sc.lights[idx];
-                    Spec4 Ls = light_L(sc, lt, lam);
-                    f3 wi, p_light; float lpdf;
+                    Spec4 Ls; f3 wi, p_light; float lpdf;
                     const f3 pm = si_p(si);
-                    if (lt.type == PM_LIGHT_UNIFORM_INFINITE) {
-                        wi = sample_uniform_sphere(u2); lpdf = PM_INV_4PI;
-                        p_light = pm + wi * (2.0f * rc.scene_radius);
-                    } else if (lt.type == PM_LIGHT_DIRECTIONAL) {
-                        wi = norm3(mk3(0.0f * lt.m[0] + 0.0f * lt.m[1] + 1.0f * lt.m[2], 0.0f * lt.m[4] + 0.0f * lt.m[5] + 1.0f * lt.m[6],
-                                       0.0f * lt.m[8] + 0.0f * lt.m[9] + 1.0f * lt.m[10]));
-                        lpdf = 1.0f;
-                        p_light = pm + wi * (2.0f * rc.scene_radius);
-                    } else {
-                        const f3 p = mk3(0.0f * lt.m[0] + 0.0f * lt.m[1] + 0.0f * lt.m[2] + lt.m[3], 0.0f * lt.m[4] + 0.0f * lt.m[5] + 0.0f * lt.m[6] + lt.m[7],
-                                         0.0f * lt.m[8] + 0.0f * lt.m[9] + 0.0f * lt.m[10] + lt.m[11]);
-                        const f3 dv = p - pm;
-                        wi = norm3(dv); lpdf = 1.0f;
-                        const float d2 = dot3(dv, dv);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) Ls.v[c] /= d2;
-                        p_light = p;
-                    }
-                    if (!spec_zero(Ls) && lpdf > 0.0f) {
+                    if (sample_light<EXT>(rc, sc, sc.lights[idx], pm, u2, lam, &Ls, &wi, &lpdf, &p_light) && !spec_zero(Ls) && lpdf > 0.0f) {
                         Spec4 f = bsdf_eval(bsdf, wo, wi);
                         const float ad = fabsf(dot3(wi, si.ns));
 #pragma unroll
@@ -433,10 +556,21 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                             const f3 dir = p_light - pm;
                             const f3 so = offset_ray_origin(si, dir);
                             const float den = prob * lpdf;
+                            float tr[4] = {1.f, 1.f, 1.f, 1.f};
+                            float s0, s1;
+                            if (EXT && use_medium && medium_segment(rc.med_bounds, so, dir, 1.0f - 0.0001f, &s0, &s1)) {
+                                const float sl = (s1 - s0) * len3(dir);
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) tr[c] = cr_exp(-sig_t[c] * sl);
+                            }
                             nt_store(pa.sh_o + slot, make_float4(so.x, so.y, so.z, 1.0f - 0.0001f));
                             nt_store(pa.sh_d + slot, make_float4(dir.x, dir.y, dir.z, 0.f));
-                            nt_store(pa.sh_L + slot, make_float4(beta[0] * f.v[0] * Ls.v[0] / den, beta[1] * f.v[1] * Ls.v[1] / den,
-                                                        beta[2] * f.v[2] * Ls.v[2] / den, beta[3] * f.v[3] * Ls.v[3] / den));
+                            if (EXT && use_medium)
+                                nt_store(pa.sh_L + slot, make_float4(beta[0] * f.v[0] * Ls.v[0] * tr[0] / den, beta[1] * f.v[1] * Ls.v[1] * tr[1] / den,
+                                                                     beta[2] * f.v[2] * Ls.v[2] * tr[2] / den, beta[3] * f.v[3] * Ls.v[3] * tr[3] / den));
+                            else
+                                nt_store(pa.sh_L + slot, make_float4(beta[0] * f.v[0] * Ls.v[0] / den, beta[1] * f.v[1] * Ls.v[1] / den,
+                                                                     beta[2] * f.v[2] * Ls.v[2] / den, beta[3] * f.v[3] * Ls.v[3] / den));
                             want_shadow = true;
                         }
                     }
@@ -473,7 +607,6 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                 specular = false;
                 wi_next = wi; ok = true;
             }
-            reinterpret_cast<uint2*>(pa.rng + slot)[0] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));   // inc never changes
             if (ok && !(beta[0] == 0.0f && beta[1] == 0.0f && beta[2] == 0.0f && beta[3] == 0.0f)) {
                 const f3 no = offset_ray_origin(si, wi_next);
                 nt_store(pa.ray_o + slot, make_float4(no.x, no.y, no.z, 0.f));
@@ -482,7 +615,9 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                 nt_store(pa.misc + slot, make_uint2((uint32_t)depth | (specular ? 1u << 8 : 0u), misc.y));
                 cont = true;
             }
+            }
         }
+        if (rng_dirty) reinterpret_cast<uint2*>(pa.rng + slot)[0] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));   // inc never changes
     }
     uint32_t oi, si_;
     block_append2(cont, count_out, want_shadow, shadow_count, lds_ab, &oi, &si_);
@@ -616,6 +751,8 @@ struct RenderState {
     std::vector<PmMaterial> mats; std::vector<std::vector<float>> mat_tables;
     std::vector<uint32_t> prim_mat;
     std::vector<PmLight> lights; std::vector<std::vector<float>> light_tables;
+    bool have_medium = false; PmMedium medium{}; std::vector<float> med_sigma_a, med_sigma_s;
+    int med_off_a = 0, med_off_s = 0; bool have_area_lights = false; int* d_prim_light = nullptr;
     PmCamera cam{}; bool have_cam = false;
     PmFilm film{}; bool have_film = false;
     std::vector<float> sensor, filter_vals;
@@ -639,7 +776,7 @@ void pm_render_state_destroy(pm_ctx* c) {
     if (!r) return;
     for (void* p : r->pa_allocs) (void)hipFree(p);
     for (hipEvent_t e : r->ev_pool) (void)hipEventDestroy(e);
-    void* ptrs[] = {r->d_pool, r->d_mats, r->d_lights, r->d_inf, r->d_prim_mat, r->d_prim_ref, r->d_patches, r->d_spheres, r->d_m9, r->d_film};
+    void* ptrs[] = {r->d_pool, r->d_mats, r->d_lights, r->d_inf, r->d_prim_mat, r->d_prim_ref, r->d_patches, r->d_spheres, r->d_m9, r->d_film, r->d_prim_light};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete r;
     c->render = nullptr;
@@ -675,12 +812,27 @@ extern "C" int pm_set_lights(pm_ctx* c, const PmLight* l, uint32_t n) {
     if (!c || (!l && n)) return fail(c, PM_ERR_INVALID, "pm_set_lights: null argument");
     RenderState* r = rs(c);
     for (uint32_t i = 0; i < n; ++i) {
-        if (l[i].type < PM_LIGHT_POINT || l[i].type > PM_LIGHT_UNIFORM_INFINITE) return fail(c, PM_ERR_INVALID, "pm_set_lights: unknown light type");
+        if (l[i].type < PM_LIGHT_POINT || l[i].type > PM_LIGHT_DIFFUSE_AREA) return fail(c, PM_ERR_INVALID, "pm_set_lights: unknown light type");
         if (!l[i].spectrum) return fail(c, PM_ERR_INVALID, "pm_set_lights: spectrum table missing");
     }
     r->lights.assign(l, l + n); r->light_tables.assign(n, {});
     for (uint32_t i = 0; i < n; ++i) { r->light_tables[i].assign(l[i].spectrum, l[i].spectrum + 471); r->lights[i].spectrum = nullptr; }
     r->scene_dirty = true;
+    return PM_OK;
+}
+extern "C" int pm_set_medium(pm_ctx* c, const PmMedium* m) {
+    if (!c) return PM_ERR_INVALID;
+    RenderState* r = rs(c);
+    r->scene_dirty = true;
+    if (!m) { r->have_medium = false; return PM_OK; }
+    if (!m->sigma_a || !m->sigma_s) return fail(c, PM_ERR_INVALID, "pm_set_medium: sigma_a and sigma_s tables (471 floats each) are required");
+    for (int k = 0; k < 3; ++k) if (!(m->bounds[k] < m->bounds[3 + k])) return fail(c, PM_ERR_INVALID, "pm_set_medium: empty bounds");
+    if (!(std::fabs(m->g) < 1.0f)) return fail(c, PM_ERR_INVALID, "pm_set_medium: |g| must be < 1");
+    r->medium = *m; r->have_medium = true;
+    r->med_sigma_a.assign(m->sigma_a, m->sigma_a + 471); r->med_sigma_s.assign(m->sigma_s, m->sigma_s + 471);
+    for (int k = 0; k < 471; ++k)
+        if (!(r->med_sigma_a[k] >= 0.0f) || !(r->med_sigma_s[k] >= 0.0f)) return fail(c, PM_ERR_INVALID, "pm_set_medium: negative coefficient");
+    r->medium.sigma_a = nullptr; r->medium.sigma_s = nullptr;
     return PM_OK;
 }
 extern "C" int pm_set_camera(pm_ctx* c, const PmCamera* cam) {
@@ -799,8 +951,22 @@ static int upload_scene(pm_ctx* c, RenderState* r) {
         dl[i].type = r->lights[i].type; dl[i].scale = r->lights[i].scale;
         std::memcpy(dl[i].m, r->lights[i].render_from_light, 48);
         dl[i].table = add_table(r->light_tables[i]);
+        dl[i].prim_id = r->lights[i].prim_id; dl[i].two_sided = r->lights[i].two_sided;
         if (dl[i].type == PM_LIGHT_UNIFORM_INFINITE) inf.push_back((int)i);   // integrators/base.rs:57-63
     }
+    // GeometricPrimitive.area_light (primitives/single.rs:13-19): one DiffuseAreaLight per emitting patch / triangle
+    std::vector<int> prim_light;
+    r->have_area_lights = false;
+    for (size_t i = 0; i < dl.size(); ++i) {
+        if (dl[i].type != PM_LIGHT_DIFFUSE_AREA) continue;
+        if (dl[i].prim_id >= n_prims) return fail(c, PM_ERR_INVALID, "pm_render: area light on a primitive id that does not exist");
+        if (prim_light.empty()) prim_light.assign(n_prims, -1);
+        prim_light[dl[i].prim_id] = (int)i;
+        r->have_area_lights = true;
+    }
+    for (const auto& sph : c->scene.spheres)
+        if (!prim_light.empty() && prim_light[sph.prim_id] >= 0) return fail(c, PM_ERR_UNSUPPORTED, "pm_render: area lights on spheres are not supported (patches and triangles only)");
+    if (r->have_medium) { r->med_off_a = add_table(r->med_sigma_a); r->med_off_s = add_table(r->med_sigma_s); }
     r->n_inf = (int)inf.size();
     r->sensor_off = add_table(r->sensor);
     // FilterSampler distribution (imaging/filter.rs:187-216, sampling/routines.rs:437-462)
@@ -852,6 +1018,7 @@ static int upload_scene(pm_ctx* c, RenderState* r) {
     if ((rc = upload(c, &r->d_prim_ref, ref))) return rc;
     if ((rc = upload(c, &r->d_patches, sp))) return rc;
     if ((rc = upload(c, &r->d_spheres, ss))) return rc;
+    if ((rc = upload(c, &r->d_prim_light, prim_light))) return rc;
     r->scene_dirty = false;
     r->geom_gen = c->geom_gen;
     return PM_OK;
@@ -884,7 +1051,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     if (!c->accel_valid) return fail(c, PM_ERR_NO_ACCEL, "pm_render: pm_build_accel has not been called");
     RenderState* r = rs(c);
     if (!r->have_cam || !r->have_film) return fail(c, PM_ERR_INVALID, "pm_render: camera and film must be set");
-    if (p->integrator != PM_INTEGRATOR_SIMPLE_PATH && p->integrator != PM_INTEGRATOR_RANDOM_WALK)
+    if (p->integrator != PM_INTEGRATOR_SIMPLE_PATH && p->integrator != PM_INTEGRATOR_RANDOM_WALK && p->integrator != PM_INTEGRATOR_VOL_PATH)
         return fail(c, PM_ERR_INVALID, "pm_render: unknown integrator");
     if (p->max_depth < 0 || p->max_depth > 254) return fail(c, PM_ERR_INVALID, "pm_render: max_depth out of range");
     const int* pb = r->film.pixel_bounds;
@@ -932,6 +1099,10 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     rc.imaging_ratio = r->film.imaging_ratio; rc.max_component_value = r->film.max_component_value;
     rc.integrator = p->integrator; rc.max_depth = p->max_depth; rc.sample_lights = p->sample_lights; rc.sample_bsdf = p->sample_bsdf;
     rc.seed = p->seed; rc.n_lights = (int)r->lights.size(); rc.n_infinite = r->n_inf;
+    rc.medium_on = (p->integrator == PM_INTEGRATOR_VOL_PATH && r->have_medium) ? 1 : 0;
+    rc.med_sigma_a = r->med_off_a; rc.med_sigma_s = r->med_off_s; rc.med_g = r->medium.g;
+    std::memcpy(rc.med_bounds, r->medium.bounds, sizeof(rc.med_bounds));
+    const bool shade_ext = rc.medium_on || r->have_area_lights;
     {   // SceneData::new -> light.preprocess(scene_bounds): Bounds3f::bounding_sphere (core/bounds.rs:588-597)
         const pm::Box& b = c->accel.bounds;
         float ctr[3], d2 = 0.0f; bool inside = true;
@@ -942,7 +1113,8 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     }
     rc.win_x0 = x0; rc.win_y0 = y0; rc.win_w = W; rc.win_h = H; rc.tiles_x = tiles_x; rc.npix_pad = (int)npix_pad;
     rc.film_x0 = pb[0]; rc.film_y0 = pb[1]; rc.film_w = pb[2] - pb[0];
-    SceneArrays sa{c->d_nodes, c->d_prims, r->d_prim_ref, r->d_patches, r->d_spheres, r->d_prim_mat, r->d_mats, r->d_lights, r->d_inf, r->d_pool};
+    SceneArrays sa{c->d_nodes, c->d_prims, r->d_prim_ref, r->d_patches, r->d_spheres, r->d_prim_mat, r->d_mats, r->d_lights, r->d_inf, r->d_pool,
+                   r->have_area_lights ? r->d_prim_light : nullptr};
     PathArrays& pa = r->pa;
     const int nb = p->max_depth + 2;
     std::vector<uint32_t> hcounts(2 * (size_t)nb);
@@ -990,7 +1162,8 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
             ++wslot;
             mark(2);
             if (random_walk) hipLaunchKernelGGL(shade_rw_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, qin, cnt_in, qout, cnt_out);
-            else hipLaunchKernelGGL(shade_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, qin, cnt_in, qout, cnt_out, cnt_sh);
+            else if (shade_ext) hipLaunchKernelGGL(shade_kernel<true>, gr, dim3(RB), 0, c->stream, rc, sa, pa, qin, cnt_in, qout, cnt_out, cnt_sh);
+            else hipLaunchKernelGGL(shade_kernel<false>, gr, dim3(RB), 0, c->stream, rc, sa, pa, qin, cnt_in, qout, cnt_out, cnt_sh);
             if (!random_walk && p->sample_lights && b < p->max_depth) {
                 mark(3);
                 if (flat) {

@@ -50,6 +50,7 @@ PMD void cr_sincos_quarter(float x, float* sn, float* cs) {
 PMD float cr_atanh(float x) { return (float)atanh((double)x); }
 PMD float cr_cosh(float x) { return (float)cosh((double)x); }
 PMD float cr_exp(float x) { return (float)exp((double)x); }
+PMD float cr_log(float x) { return (float)log((double)x); }
 
 #define PM_PI 3.14159265358979323846f
 #define PM_INV_PI 0.318309886183790671537767526745028724f
@@ -101,7 +102,7 @@ PMD float rng_uniform(Rng* r) {
 // ---------------------------------------------------------------------------------------- spectra
 struct DSpectrum { int kind; float a, b, c, d; int table; };   // table: offset into the float pool
 struct DMaterial { int type; DSpectrum spec; float ur, vr; int remap; };
-struct DLight { int type; float scale; float m[12]; int table; };
+struct DLight { int type; float scale; float m[12]; int table; uint32_t prim_id; int two_sided; };
 
 PMD float dense_at(const float* __restrict__ pool, int table, float lambda) {
     const float r = roundf(lambda);
@@ -226,6 +227,9 @@ struct RenderConst {
     uint32_t seed;
     int n_lights, n_infinite;
     float scene_radius;
+    // homogeneous medium of PM_INTEGRATOR_VOL_PATH (media/medium.rs:41-97): 471-entry tables in the pool, HG g, bounds
+    int medium_on, med_sigma_a, med_sigma_s;
+    float med_g, med_bounds[6];
     // pass geometry
     int win_x0, win_y0, win_w, win_h, tiles_x, npix_pad;
     int film_x0, film_y0, film_w;
@@ -392,6 +396,110 @@ PMD SurfInt sphere_interaction(const DShadeSphere& s, f3 ro, f3 rd, float t_hit)
                    dpdu.x * m[8] + dpdu.y * m[9] + dpdu.z * m[10]);
     si.ns = face_fwd(xf_normal12(s.ofr, n), si.n);
     return si;
+}
+
+// ---------------------------------------------------------------------------------------- area lights, medium (extensions)
+// sampling/routines.rs:219-246 (B14 reproduced: sample_bilinear hands (y, w0, w2) to the (a, b, t) lerp)
+PMD float bilinear_pdf(f2 p, const float* w) {
+    float w_sum = 0.0f;
+    for (int i = 0; i < 4; ++i) w_sum += w[i];
+    if (p.x < 0.0f || p.x > 1.0f || p.y < 0.0f || p.y > 1.0f) return 0.0f;
+    if (w_sum == 0.0f) return 1.0f;
+    return 4.0f * ((1.0f - p.x) * (1.0f - p.y) * w[0] + p.x * (1.0f - p.y) * w[1] + p.y * (1.0f - p.x) * w[2] + p.x * p.y * w[3]) / w_sum;
+}
+PMD f2 sample_bilinear(f2 u, const float* w) {
+    f2 r;
+    r.y = sample_linear(u.y, w[0] + w[1], w[2] + w[3]);
+    r.x = sample_linear(u.x, lerpf(r.y, w[0], w[2]), lerpf(r.y, w[1], w[3]));
+    return r;
+}
+// media/phase_function.rs:57-80
+PMD float henyey_greenstein(float cos_theta, float g) {
+    const float denom = 1.0f + g * g + 2.0f * g * cos_theta;
+    return PM_INV_4PI * (1.0f - g * g) / (denom * safe_sqrtf(denom));
+}
+PMD f3 sample_henyey_greenstein(f3 wo, float g, f2 u, float* pdf) {
+    float cos_theta;
+    if (fabsf(g) < 1e-3f) cos_theta = 1.0f - 2.0f * u.x;
+    else {
+        const float q = (1.0f - g * g) / (1.0f + g - 2.0f * g * u.x);
+        cos_theta = -1.0f / (2.0f * g) * (1.0f + g * g - q * q);
+    }
+    const float sin_theta = safe_sqrtf(1.0f - cos_theta * cos_theta);
+    const float phi = 2.0f * PM_PI * u.y;
+    f3 x, y;                                           // Frame::from_z(wo) via Vec3f::coordinate_system (core/vec.rs:743-757)
+    if (fabsf(wo.x) > fabsf(wo.y)) x = mk3(-wo.z, 0.0f, wo.x) / sqrtf(wo.x * wo.x + wo.z * wo.z);
+    else x = mk3(0.0f, wo.z, -wo.y) / sqrtf(wo.y * wo.y + wo.z * wo.z);
+    y = cross3(wo, x);
+    const float st = clampf(sin_theta, -1.0f, 1.0f), ct = clampf(cos_theta, -1.0f, 1.0f);
+    float sp, cp; cr_sincos(phi, &sp, &cp);
+    *pdf = henyey_greenstein(cos_theta, g);
+    return (st * cp) * x + (st * sp) * y + ct * wo;
+}
+// shapes/bilinear_patch.rs:739-773
+PMD bool f3_eq(f3 a, f3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+PMD float dist2(f3 a, f3 b) { const f3 d = a - b; return dot3(d, d); }
+PMD bool patch_is_rectangle(f3 p00, f3 p10, f3 p01, f3 p11) {
+    if (f3_eq(p00, p01) || f3_eq(p01, p11) || f3_eq(p11, p10) || f3_eq(p10, p00)) return false;
+    const f3 n = norm3(cross3(p10 - p00, p01 - p00));
+    if (fabsf(dot3(norm3(p11 - p00), n)) > 1e-5f) return false;
+    const f3 c = (p00 + p10 + p01 + p11) / 4.0f;
+    const float d0 = dist2(p00, c), d1 = dist2(p10, c), d2 = dist2(p01, c), d3 = dist2(p11, c);
+    if (fabsf(d0 - d0) / d0 > 1e-4f || fabsf(d1 - d0) / d0 > 1e-4f || fabsf(d2 - d0) / d0 > 1e-4f || fabsf(d3 - d0) / d0 > 1e-4f) return false;
+    return true;
+}
+struct ShapeSample { f3 p; f3 n; float pdf; };
+// BilinearPatch::sample + the area-sampling branch of sample_with_context (bilinear_patch.rs:260-352); the spherical-
+// rectangle branch is todo!() upstream (sampling/routines.rs:307-327), so every patch is sampled by area
+PMD bool patch_sample_ctx(const DShadePatch& sp, const float* __restrict__ pool, f3 ref_p, f2 u, ShapeSample* out) {
+    const f3 p00 = mk3(sp.p[0], sp.p[1], sp.p[2]), p10 = mk3(sp.p[3], sp.p[4], sp.p[5]);
+    const f3 p01 = mk3(sp.p[6], sp.p[7], sp.p[8]), p11 = mk3(sp.p[9], sp.p[10], sp.p[11]);
+    f2 uv; float pdf;
+    if (!patch_is_rectangle(p00, p10, p01, p11)) {
+        const float w[4] = {len3(cross3(p10 - p00, p01 - p00)), len3(cross3(p10 - p00, p11 - p10)),
+                            len3(cross3(p01 - p00, p11 - p01)), len3(cross3(p11 - p10, p11 - p01))};
+        uv = sample_bilinear(u, w); pdf = bilinear_pdf(uv, w);
+    } else { uv = u; pdf = 1.0f; }
+    const f3 pu0 = lerp3(p00, p01, uv.y), pu1 = lerp3(p10, p11, uv.y);
+    const f3 pt = lerp3(pu0, pu1, uv.x);
+    const f3 dpdu = pu1 - pu0;
+    const f3 dpdv = lerp3(p01, p11, uv.x) - lerp3(p00, p10, uv.x);
+    if (dot3(dpdu, dpdu) == 0.0f || dot3(dpdv, dpdv) == 0.0f) return false;
+    f3 n = norm3(cross3(dpdu, dpdv));
+    if (sp.flags & 2u) {
+        const float* q = pool + sp.nrm_off;
+        const f3 n00 = mk3(q[0], q[1], q[2]), n10 = mk3(q[3], q[4], q[5]), n01 = mk3(q[6], q[7], q[8]), n11 = mk3(q[9], q[10], q[11]);
+        const f3 ns = lerp3(lerp3(n00, n01, uv.y), lerp3(n10, n11, uv.y), uv.x);
+        n = face_fwd(n, ns);
+    } else if (sp.flags & 1u) n = -n;
+    pdf = pdf / len3(cross3(dpdu, dpdv));
+    // Point3fi::new_fi(p, p_err).midpoints(): the interval is [down(p - e), up(p + e)]
+    const f3 pabs = abs3(p00) + abs3(p01) + abs3(p10) + abs3(p11);
+    const f3 perr = pabs * gamma_n(6);
+    const f3 pm = mk3(iv_mid(iv_err(pt.x, perr.x)), iv_mid(iv_err(pt.y, perr.y)), iv_mid(iv_err(pt.z, perr.z)));
+    f3 wi = pm - ref_p;
+    if (dot3(wi, wi) == 0.0f) return false;
+    wi = norm3(wi);
+    pdf /= fabsf(dot3(n, -wi)) / dist2(ref_p, pm);
+    if (isinf(pdf)) return false;
+    out->p = pm; out->n = n; out->pdf = pdf;
+    return true;
+}
+// the part [t0, t1] of the ray's [0, t_max] inside the medium's bounds
+PMD bool medium_segment(const float* b, f3 ro, f3 rd, float t_max, float* t0o, float* t1o) {
+    float t0 = 0.0f, t1 = t_max;
+    const float o[3] = {ro.x, ro.y, ro.z}, d[3] = {rd.x, rd.y, rd.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float inv = 1.0f / d[a];
+        float tn = (b[a] - o[a]) * inv, tf = (b[3 + a] - o[a]) * inv;
+        if (tn > tf) { const float x = tn; tn = tf; tf = x; }
+        if (tn > t0) t0 = tn;
+        if (tf < t1) t1 = tf;
+    }
+    if (!(t0 < t1)) return false;
+    *t0o = t0; *t1o = t1;
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------- BxDFs

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 from . import _capi
-from ._capi import (PM_FILTER_BOX, PM_FILTER_GAUSSIAN, PM_LIGHT_DIRECTIONAL, PM_LIGHT_POINT,
+from ._capi import (PM_FILTER_BOX, PM_FILTER_GAUSSIAN, PM_LIGHT_DIFFUSE_AREA, PM_LIGHT_DIRECTIONAL, PM_LIGHT_POINT,
                     PM_LIGHT_UNIFORM_INFINITE, PM_MAT_DIELECTRIC, PM_MAT_DIFFUSE, PM_SPEC_CONSTANT, PM_SPEC_DENSE,
                     PM_SPEC_RGB_ALBEDO, PmCamera, PmFilm, PmLight, PmMaterial, PmSpectrum)
 
@@ -196,6 +196,21 @@ def light(kind, table, scale, render_from_light=None):
     return {"type": kind, "scale": float(np.float32(scale)), "m": m, "table": _f32(table)}
 
 
+def area_light(table, scale, prim_id, two_sided=False):
+    """DiffuseAreaLight (extension) on the patch / triangle `prim_id`: L = scale * spectrum on the normal's side"""
+    l = light(PM_LIGHT_DIFFUSE_AREA, table, scale)
+    l.update(prim_id=int(prim_id), two_sided=bool(two_sided))
+    return l
+
+
+def homogeneous_medium(sigma_a, sigma_s, sigma_scale=1.0, g=0.0, bounds=None):
+    """HomogeneousMedium::new(sigma_a, sigma_s, sigma_scale, emission = 0, g) (media/medium.rs:49-68): 471-entry tables of the
+    two coefficients, scaled; bounds = (min xyz, max xyz) in render space, None = everywhere"""
+    b = (-np.inf,) * 3 + (np.inf,) * 3 if bounds is None else tuple(float(x) for x in bounds)
+    return {"sigma_a": _f32(sigma_a) * np.float32(sigma_scale), "sigma_s": _f32(sigma_s) * np.float32(sigma_scale),
+            "g": float(g), "bounds": b}
+
+
 class SceneDescription:
     """Everything `SimplePathIntegrator::new(...)` + `render()` consume, flattened."""
 
@@ -204,6 +219,7 @@ class SceneDescription:
         self.prim_materials = []   # one material id per primitive (meshes contribute one id per face)
         self.materials = []
         self.lights = []
+        self.medium = None         # homogeneous_medium(...) or None
         self.camera = None         # PmCamera
         self.film = None           # dict, see make_film
         self.render_from_world = None
@@ -234,7 +250,20 @@ class SceneDescription:
             arr[i].render_from_light[:] = l["m"].reshape(-1).tolist()
             self._keep.append(l["table"])
             arr[i].spectrum = l["table"].ctypes.data_as(C.POINTER(C.c_float))
+            arr[i].prim_id = l.get("prim_id", 0)
+            arr[i].two_sided = int(l.get("two_sided", False))
         return arr
+
+    def c_medium(self):
+        if self.medium is None:
+            return None
+        m = _capi.PmMedium()
+        self._keep += [self.medium["sigma_a"], self.medium["sigma_s"]]
+        m.sigma_a = self.medium["sigma_a"].ctypes.data_as(C.POINTER(C.c_float))
+        m.sigma_s = self.medium["sigma_s"].ctypes.data_as(C.POINTER(C.c_float))
+        m.g = self.medium["g"]
+        m.bounds[:] = list(self.medium["bounds"])
+        return m
 
     def c_prim_materials(self):
         return np.ascontiguousarray(self.prim_materials, dtype=np.uint32)

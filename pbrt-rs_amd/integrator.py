@@ -29,6 +29,9 @@ class WavefrontIntegrator:
         ck(self._lib.pm_set_prim_materials(self._h, pmat.ctypes.data, len(pmat)))
         lights = scene.c_lights()
         ck(self._lib.pm_set_lights(self._h, lights, len(scene.lights)))
+        med = scene.c_medium() if getattr(scene, "medium", None) is not None else None
+        if med is not None:
+            ck(self._lib.pm_set_medium(self._h, C.byref(med)))
         ck(self._lib.pm_set_camera(self._h, C.byref(scene.camera)))
         film = scene.c_film()
         ck(self._lib.pm_set_film(self._h, C.byref(film)))

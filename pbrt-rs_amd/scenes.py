@@ -195,10 +195,13 @@ def blob_sky_scene(n_blobs=20480, resolution=(3840, 2160), seed=3, spectra=None,
     return sd
 
 
-def cornell_scene(resolution=(1024, 1024), spectra=None, glass_sphere=True):
+def cornell_scene(resolution=(1024, 1024), spectra=None, glass_sphere=True, area_light=False, medium=None):
     """C2: a Cornell box built from triangles (walls, tall box, short box), lit by a PointLight just under the
     ceiling (the reference has no area light, lights/base.rs:18-22), seen through a PerspectiveCamera.
-    Optionally one smooth dielectric sphere (divergent specular paths)."""
+    Optionally one smooth dielectric sphere (divergent specular paths).
+    area_light: instead of the point light, a 0.5 x 0.5 quad emitter (one bilinear patch, DiffuseAreaLight extension)
+    just under the ceiling, facing down.  medium: (sigma_a, sigma_s, g) of a grey homogeneous medium filling the box
+    (C5, BASELINE.json configs[4]; render it with PM_INTEGRATOR_VOL_PATH)."""
     from . import host
     from .aggregate import Sphere, TriangleMesh
     f32 = np.float32
@@ -249,7 +252,29 @@ def cornell_scene(resolution=(1024, 1024), spectra=None, glass_sphere=True):
         t = rfw * host.Transform.translate((0.4, -0.1, 0.3))
         sd.prims.append(Sphere(0.3, -0.3, 0.3, 360.0, t.m, t.m_inv, False))
         sd.prim_materials.append(glass)
-    lt = rfw * host.Transform.translate((0.0, 0.9, 0.0))
     table = sp.d65.copy()
-    sd.lights = [host.light(host.PM_LIGHT_POINT, table, f32(4.0) / f32(sp.photometric(table)), lt.m)]
+    if area_light:
+        from .aggregate import BilinearPatchMesh
+        # p00 p10 p01 p11 ordered so that dpdu x dpdv points down (-y): the emitting side faces the room
+        quad_pos = _xf_points(rfw.m, np.asarray([[-0.25, 0.98, -0.25], [0.25, 0.98, -0.25], [-0.25, 0.98, 0.25], [0.25, 0.98, 0.25]], f32))
+        sd.prims.append(BilinearPatchMesh(quad_pos, [[0, 1, 2, 3]]))
+        sd.prim_materials.append(white)
+        emitter_id = len(sd.prim_materials) - 1
+        # same flux as the 4 / Y point light: Phi = 4 pi I = pi A L  =>  L = 4 I / A
+        sd.lights = [host.area_light(table, f32(4.0 * 4.0 / 0.25) / f32(sp.photometric(table)), emitter_id, two_sided=False)]
+    else:
+        lt = rfw * host.Transform.translate((0.0, 0.9, 0.0))
+        sd.lights = [host.light(host.PM_LIGHT_POINT, table, f32(4.0) / f32(sp.photometric(table)), lt.m)]
+    if medium is not None:
+        sigma_a, sigma_s, g = medium
+        lo = _xf_points(rfw.m, np.asarray([[-1.0, -1.0, -1.0]], f32))[0]
+        hi = _xf_points(rfw.m, np.asarray([[1.0, 1.0, 1.0]], f32))[0]
+        sd.medium = host.homogeneous_medium(sp.constant_table(sigma_a), sp.constant_table(sigma_s), 1.0, g,
+                                            bounds=tuple(np.minimum(lo, hi)) + tuple(np.maximum(lo, hi)))
     return sd
+
+
+def c5_scene(resolution=(1024, 1024), spectra=None):
+    """BASELINE.json configs[4] / SURVEY 8(d) C5: the C2 box + ceiling quad emitter + homogeneous medium filling the box
+    (sigma_s = 1.0, sigma_a = 0.05 per unit length, grey; g = 0.6); rendered with PM_INTEGRATOR_VOL_PATH at max_depth 16."""
+    return cornell_scene(resolution, spectra, glass_sphere=True, area_light=True, medium=(0.05, 1.0, 0.6))

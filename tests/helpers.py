@@ -24,6 +24,9 @@ def oracle_renderer_from(sd, ora, split=None):
     mats, lights, film = sd.c_materials(), sd.c_lights(), sd.c_film()
     r = ora.Renderer(sc, mats, len(sd.materials), sd.c_prim_materials(), lights, len(sd.lights), sd.camera, film)
     r._keep = (sc, mats, lights, film, sd)
+    if getattr(sd, "medium", None) is not None:
+        m = sd.medium
+        r.set_medium(m["sigma_a"], m["sigma_s"], m["g"], m["bounds"])
     return r
 
 
