@@ -27,7 +27,8 @@ __device__ __forceinline__ void nt_store(float4* p, float4 v) { nt_f4 t; t.x = v
 __device__ __forceinline__ void nt_store(uint2* p, uint2 v) { nt_u2 t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, reinterpret_cast<nt_u2*>(p)); }
 __device__ __forceinline__ float4 nt_load(const float4* p) { const nt_f4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p)); return make_float4(t.x, t.y, t.z, t.w); }
 #ifndef PM_SHADE_WAVES_PER_EU
-#define PM_SHADE_WAVES_PER_EU 0
+#define PM_SHADE_WAVES_PER_EU 5     // 96 VGPRs; measured with the dense path-state layout (scripts/ab_c4s.sh): 5 beats the
+                                    // compiler's own 4 by 5 %, 6 (80 VGPRs, spills) loses 11 %.  RB = 256: 128, 512, 1024 all lose
 #endif
 #if PM_SHADE_WAVES_PER_EU > 0
 #define PM_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(PM_SHADE_WAVES_PER_EU, PM_SHADE_WAVES_PER_EU)))
@@ -38,15 +39,33 @@ __device__ __forceinline__ float4 nt_load(const float4* p) { const nt_f4 t = __b
 
 using namespace pmd;
 
+// Path state.  The state a bounce needs FOLLOWS THE QUEUE: entry i of the current queue lives at index i of generation g of
+// the arrays below, and the shade pass writes the survivors - compacted - into generation g ^ 1 at their index in the next
+// queue.  Every kernel therefore reads and writes dense, coalesced ranges whatever fraction of the paths is still alive
+// (round 1 addressed twelve arrays by the path's original slot through an index queue: after compaction the gathers were
+// sparse, and the same kernel moved 2.5 TB/s with every fourth slot missing against 5.3 TB/s dense, profiles/r01/bw_probe.log).
+// Only what is touched once or rarely stays addressed by slot (pixel-in-8x8-tile order x sample): the radiance sum L
+// (added to by unoccluded shadow rays and escaped rays), and what accumulate_kernel needs at the end.
+#define PM_DEAD 0xFFFFFFFFu
+#define PM_CNT_STRIDE 64
+#define PM_PATH_BYTES (2 * (16 + 16 + 16 + 16 + 8) + 16 + 48 + 16 + 16 + 16 + 4)       /* device bytes per path of a pass */
 struct PathArrays {
-    float4 *ray_o, *ray_d, *beta, *L, *lambda, *pdf, *hit, *sh_o, *sh_d, *sh_L;
-    uint4* rng;
-    uint2* misc;          // x: depth | specular << 8 ; y: filter weight bits
-    uint32_t *q0, *q1, *shq;
-    uint32_t* counts;     // [2 * (max_depth + 2)]: active count per bounce, shadow count per bounce
+    float4* ro[2];      // xyz ray origin, w = slot (uint bits)
+    float4* rd[2];      // xyz ray direction, w = depth | specular_bounce << 8 (uint bits); PM_DEAD = padded slot of a ragged window
+    float4* beta[2];
+    float4* lambda[2];
+    uint2* rng[2];      // PCG32 state; the increment follows from the slot's sample index (rng_inc_of)
+    float4* hit;        // per entry of the current queue: closest-hit writes, shade reads
+    float4 *sh_o, *sh_d, *sh_L;     // per entry of the SHADOW queue: origin + t_max, direction + slot, contribution if unoccluded
+    float4 *L, *lambda_s, *pdf;     // per slot
+    float* fw;                      // per slot: filter weight
+    uint32_t* counts;     // 2 * (max_depth + 2) counters, PM_CNT_STRIDE words apart: active count per bounce, then shadow count
+                          // per bounce.  Every block of a shade pass adds to two of them with one atomic each: on separate
+                          // 256-byte lines the two streams of same-address atomics do not queue behind each other
     float4* rw_f;         // RandomWalk only: f * |cos| of bounce d of path `slot` at rw_f[d * cap + slot]
-    uint32_t cap;         // slots per array
+    uint32_t cap;         // entries per array
 };
+__device__ __forceinline__ float4 with_w(f3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
 struct SceneArrays {
     const PmWideNode* nodes; const uint4* prims;
     const uint32_t* prim_ref;        // prim id -> type << 30 | index into shade arrays
@@ -56,6 +75,10 @@ struct SceneArrays {
     const int* prim_light;           // prim id -> index of the DiffuseAreaLight on it, or -1 (null: the scene has no area light)
 };
 
+__device__ __forceinline__ unsigned long long rng_inc_of(const RenderConst& rc, uint32_t slot) {     // rng_start, dimension 0
+    const unsigned long long s = (unsigned long long)(rc.s_base + (int)(slot / (uint32_t)rc.npix_pad));
+    return ((s * 65536ULL) << 1) | 1ULL;
+}
 __device__ __forceinline__ bool slot_pixel(const RenderConst& rc, uint32_t slot, int* px, int* py, int* s) {
     const uint32_t p = slot % (uint32_t)rc.npix_pad;
     *s = rc.s_base + (int)(slot / (uint32_t)rc.npix_pad);
@@ -72,12 +95,10 @@ __global__ __launch_bounds__(RB) void raygen_kernel(RenderConst rc, SceneArrays 
     if (slot >= npaths) return;
     int px, py, s;
     const bool inside = slot_pixel(rc, slot, &px, &py, &s);
-    pa.q0[slot] = slot;     // queue 0 is the identity; padded slots are retired by the first shade pass
-    if (slot == 0) pa.counts[0] = npaths;
-    if (!inside) {      // padded slot of a ragged window: dead (ray_o.w != 0 tells the closest-hit fetch without a misc load)
-        pa.misc[slot] = make_uint2(0xFFFFFFFFu, 0u);
+    if (slot == 0) pa.counts[0] = npaths;     // queue 0 is the identity: entry i holds slot i
+    if (!inside) {      // padded slot of a ragged window: a dead entry, retired by the first shade pass
+        pa.rd[0][slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(PM_DEAD));
         pa.L[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-        pa.ray_o[slot] = make_float4(0.f, 0.f, 0.f, 1.f);
         return;
     }
     Rng rng = rng_start(px, py, rc.seed, (unsigned long long)s, 0ull);
@@ -99,34 +120,34 @@ __global__ __launch_bounds__(RB) void raygen_kernel(RenderConst rc, SceneArrays 
     f2 pl; pl.x = rng_uniform(&rng); pl.y = rng_uniform(&rng);
     f3 o, d;
     generate_camera_ray(rc, pf, pl, &o, &d);
-    pa.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.f);
-    pa.ray_d[slot] = make_float4(d.x, d.y, d.z, 0.f);
-    pa.beta[slot] = make_float4(1.f, 1.f, 1.f, 1.f);
+    pa.ro[0][slot] = with_w(o, slot);
+    pa.rd[0][slot] = with_w(d, 0u | (1u << 8));                    // depth 0, specular_bounce = true
+    pa.beta[0][slot] = make_float4(1.f, 1.f, 1.f, 1.f);
+    pa.lambda[0][slot] = make_float4(lam[0], lam[1], lam[2], lam[3]);
+    pa.rng[0][slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
     pa.L[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-    pa.lambda[slot] = make_float4(lam[0], lam[1], lam[2], lam[3]);
+    pa.lambda_s[slot] = make_float4(lam[0], lam[1], lam[2], lam[3]);
     pa.pdf[slot] = make_float4(pdf[0], pdf[1], pdf[2], pdf[3]);
-    pa.rng[slot] = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), (uint32_t)rng.inc, (uint32_t)(rng.inc >> 32));
-    pa.misc[slot] = make_uint2(0u | (1u << 8), __float_as_uint(fw));   // depth 0, specular_bounce = true
+    pa.fw[slot] = fw;
 }
 
 // ------------------------------------------------------------------------------------------ traversal
 template <bool COUNT, bool MIXED>
-__global__ __launch_bounds__(TB) PM_TRAV_ATTR(false, MIXED) void closest_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(TB) PM_TRAV_ATTR(false, MIXED) void closest_kernel(SceneArrays sc, PathArrays pa, uint32_t g,
                                                      const uint32_t* __restrict__ count, uint32_t* __restrict__ work, uint32_t refill,
                                                      uint4* __restrict__ defer_list, uint32_t defer_cap, unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
     __shared__ uint32_t cand[2 * PM_CAND_MAX * TB];     // units, then t lower bounds
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
-        const uint32_t slot = queue[i];
-        const float4 o = pa.ray_o[slot];
-        if (o.w != 0.0f) return false;          // dead slot (raygen)
-        const float4 d = pa.ray_d[slot];
+        const float4 d = pa.rd[g][i];
+        if (__float_as_uint(d.w) == PM_DEAD) return false;          // dead entry (raygen)
+        const float4 o = pa.ro[g][i];
         ray->o = mk3(o.x, o.y, o.z); ray->d = mk3(d.x, d.y, d.z); ray->tmax = INFINITY;
         return true;
     };
     auto commit = [&](uint32_t i, bool found, const HitRec& h) {
-        pa.hit[queue[i]] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
+        pa.hit[i] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
     };
     trace_persistent<false, COUNT, MIXED>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB,
                                    defer_list, work + PM_WORK_SLOTS, defer_cap, &tc, fetch, commit);
@@ -144,16 +165,15 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR(true, MIXED) void shadow_kernel(Sc
     __shared__ uint32_t cand[2 * PM_CAND_MAX * TB];     // units, then t lower bounds
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
-        const uint32_t slot = pa.shq[i];
-        const float4 o = pa.sh_o[slot], d = pa.sh_d[slot];
+        const float4 o = pa.sh_o[i], d = pa.sh_d[i];
         ray->o = mk3(o.x, o.y, o.z); ray->d = mk3(d.x, d.y, d.z); ray->tmax = o.w;
         return true;
     };
     auto commit = [&](uint32_t i, bool occluded, const HitRec&) {
         if (!occluded) {
-            const uint32_t slot = pa.shq[i];
+            const uint32_t slot = __float_as_uint(pa.sh_d[i].w);
             float4 L = pa.L[slot];
-            const float4 c = pa.sh_L[slot];
+            const float4 c = pa.sh_L[i];
             L.x += c.x; L.y += c.y; L.z += c.z; L.w += c.w;
             pa.L[slot] = L;
         }
@@ -168,22 +188,21 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR(true, MIXED) void shadow_kernel(Sc
 }
 // flat-sweep variants for scenes of at most PM_FLAT_MAX_PRIMS primitives (pm_device.hpp trace_flat)
 template <bool COUNT, bool PATCH>
-__global__ __launch_bounds__(TB) PM_FLAT_ATTR void closest_flat_kernel(PmFlatScene fs, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(TB) PM_FLAT_ATTR void closest_flat_kernel(PmFlatScene fs, SceneArrays sc, PathArrays pa, uint32_t g,
                                                           const uint32_t* __restrict__ count, uint4* __restrict__ defer_list, uint32_t defer_cap,
                                                           uint32_t* __restrict__ defer_count, uint32_t* __restrict__ slow_list,
                                                           unsigned long long* __restrict__ counters) {
     __shared__ uint32_t cand[3 * PM_FLAT_CAND_MAX * TB];     // units, then the lower bounds of t as fractions (numerators, denominators)
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
-        const uint32_t slot = queue[i];
-        const float4 o = pa.ray_o[slot];
-        if (o.w != 0.0f) return false;          // dead slot (raygen)
-        const float4 d = pa.ray_d[slot];
+        const float4 d = pa.rd[g][i];
+        if (__float_as_uint(d.w) == PM_DEAD) return false;          // dead entry (raygen)
+        const float4 o = pa.ro[g][i];
         ray->o = mk3(o.x, o.y, o.z); ray->d = mk3(d.x, d.y, d.z); ray->tmax = INFINITY;
         return true;
     };
     auto commit = [&](uint32_t i, bool found, const HitRec& h) {
-        pa.hit[queue[i]] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
+        pa.hit[i] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
     };
     trace_flat<false, COUNT, PATCH>(fs, sc.prims, *count, cand + threadIdx.x, TB, defer_list, defer_count, slow_list,
                              defer_count + PM_WORK_SLOTS, defer_cap, &tc, fetch, commit);
@@ -200,16 +219,15 @@ __global__ __launch_bounds__(TB) PM_FLAT_ATTR void shadow_flat_kernel(PmFlatScen
     __shared__ uint32_t cand[3 * PM_FLAT_CAND_MAX * TB];     // units, then the lower bounds of t as fractions (numerators, denominators)
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
-        const uint32_t slot = pa.shq[i];
-        const float4 o = pa.sh_o[slot], d = pa.sh_d[slot];
+        const float4 o = pa.sh_o[i], d = pa.sh_d[i];
         ray->o = mk3(o.x, o.y, o.z); ray->d = mk3(d.x, d.y, d.z); ray->tmax = o.w;
         return true;
     };
     auto commit = [&](uint32_t i, bool occluded, const HitRec&) {
         if (!occluded) {
-            const uint32_t slot = pa.shq[i];
+            const uint32_t slot = __float_as_uint(pa.sh_d[i].w);
             float4 L = pa.L[slot];
-            const float4 c = pa.sh_L[slot];
+            const float4 c = pa.sh_L[i];
             L.x += c.x; L.y += c.y; L.z += c.z; L.w += c.w;
             pa.L[slot] = L;
         }
@@ -224,19 +242,18 @@ __global__ __launch_bounds__(TB) PM_FLAT_ATTR void shadow_flat_kernel(PmFlatScen
 }
 // second pass (pm_device.hpp deferred_fix): exact tests of what the kernels above deferred, with the same fetch / commit
 template <bool COUNT>
-__global__ __launch_bounds__(TB) void closest_fix_kernel(PmFlatScene fs, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(TB) void closest_fix_kernel(PmFlatScene fs, SceneArrays sc, PathArrays pa, uint32_t g,
                                                          const uint4* __restrict__ defer_list, uint32_t defer_cap, const uint32_t* __restrict__ defer_count,
                                                          const uint32_t* __restrict__ slow_list, unsigned long long* __restrict__ counters) {
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
-        const uint32_t slot = queue[i];
-        const float4 o = pa.ray_o[slot], d = pa.ray_d[slot];
+        const float4 o = pa.ro[g][i], d = pa.rd[g][i];
         ray->o = mk3(o.x, o.y, o.z); ray->d = mk3(d.x, d.y, d.z); ray->tmax = INFINITY;
         return true;
     };
-    auto load_t = [&](uint32_t i) -> float { return pa.hit[queue[i]].y; };
+    auto load_t = [&](uint32_t i) -> float { return pa.hit[i].y; };
     auto commit = [&](uint32_t i, bool found, const HitRec& h) {
-        pa.hit[queue[i]] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
+        pa.hit[i] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
     };
     __shared__ uint4 gather[128 * (TB / 64)];
     deferred_fix<false, COUNT>(fs, sc.prims, defer_list, defer_count, slow_list, defer_count + PM_WORK_SLOTS, defer_cap,
@@ -250,17 +267,16 @@ __global__ __launch_bounds__(TB) void shadow_fix_kernel(PmFlatScene fs, SceneArr
                                                         unsigned long long* __restrict__ counters) {
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
-        const uint32_t slot = pa.shq[i];
-        const float4 o = pa.sh_o[slot], d = pa.sh_d[slot];
+        const float4 o = pa.sh_o[i], d = pa.sh_d[i];
         ray->o = mk3(o.x, o.y, o.z); ray->d = mk3(d.x, d.y, d.z); ray->tmax = o.w;
         return true;
     };
     auto load_t = [&](uint32_t) -> float { return 0.0f; };
     auto commit = [&](uint32_t i, bool occluded, const HitRec&) {
         if (!occluded) {
-            const uint32_t slot = pa.shq[i];
+            const uint32_t slot = __float_as_uint(pa.sh_d[i].w);
             float4 L = pa.L[slot];
-            const float4 c = pa.sh_L[slot];
+            const float4 c = pa.sh_L[i];
             L.x += c.x; L.y += c.y; L.z += c.z; L.w += c.w;
             pa.L[slot] = L;
         }
@@ -387,34 +403,39 @@ __device__ __forceinline__ bool sample_light(const RenderConst& rc, const SceneA
 // a hit, shape sampling, the medium event as a third outcome beside "surface" and "escaped") is compiled only into the EXT
 // variant: it costs registers, and the plain variant is the hot kernel of the C2 / C4 frames.
 template <bool EXT>
-__global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ qin,
-                                                   const uint32_t* __restrict__ count_in, uint32_t* __restrict__ qout,
+__global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc, SceneArrays sc, PathArrays pa, uint32_t g,
+                                                   const uint32_t* __restrict__ count_in,
                                                    uint32_t* __restrict__ count_out, uint32_t* __restrict__ shadow_count) {
     __shared__ uint32_t lds_ab[2 * (RB / 64 + 1)];
     const uint32_t i = blockIdx.x * RB + threadIdx.x;
     const uint32_t n_in = *count_in;
     if (blockIdx.x * RB >= n_in) return;             // whole block idle (uniform exit, before any barrier)
     bool cont = false, want_shadow = false;
-    uint32_t slot = 0;
+    // what this lane hands on, written after the block-wide appends at its index in the next / the shadow queue
+    uint32_t slot = 0, c_misc = 0;
+    f3 c_o = mk3(0.f, 0.f, 0.f), c_d = mk3(0.f, 0.f, 0.f), s_d = mk3(0.f, 0.f, 0.f);
+    float4 s_o = make_float4(0.f, 0.f, 0.f, 0.f), s_L = make_float4(0.f, 0.f, 0.f, 0.f);
+    float beta[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 l4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    Rng rng; rng.state = 0ull; rng.inc = 0ull;
     const bool live = i < n_in;
-    if (live) slot = qin[i];
-    uint2 misc = live ? pa.misc[slot] : make_uint2(0xFFFFFFFFu, 0u);
-    if (live && misc.x != 0xFFFFFFFFu) {
-        const float4 hv = nt_load(pa.hit + slot);
+    const float4 rd4 = live ? nt_load(pa.rd[g] + i) : make_float4(0.f, 0.f, 0.f, __uint_as_float(PM_DEAD));
+    const uint32_t mw = __float_as_uint(rd4.w);
+    if (live && mw != PM_DEAD) {
+        const float4 ro4 = nt_load(pa.ro[g] + i);
+        slot = __float_as_uint(ro4.w);
+        const float4 hv = nt_load(pa.hit + i);
         const uint32_t prim_id = __float_as_uint(hv.x);
-        float4 b4 = nt_load(pa.beta + slot);
-        const float4 l4 = nt_load(pa.lambda + slot);
-        float beta[4] = {b4.x, b4.y, b4.z, b4.w};
+        const float4 b4 = nt_load(pa.beta[g] + i);
+        l4 = nt_load(pa.lambda[g] + i);
+        beta[0] = b4.x; beta[1] = b4.y; beta[2] = b4.z; beta[3] = b4.w;
         const float lam[4] = {l4.x, l4.y, l4.z, l4.w};
-        int depth = (int)(misc.x & 0xFFu);
-        bool specular = ((misc.x >> 8) & 1u) != 0u;
-        const float4 rd4 = nt_load(pa.ray_d + slot);
+        int depth = (int)(mw & 0xFFu);
+        bool specular = ((mw >> 8) & 1u) != 0u;
         const f3 rd = mk3(rd4.x, rd4.y, rd4.z);
-        Rng rng; rng.state = 0ull; rng.inc = 0ull;
-        bool rng_dirty = false;
-        if (EXT) {
-            const uint4 r4 = pa.rng[slot];
-            rng.state = ((unsigned long long)r4.y << 32) | r4.x; rng.inc = ((unsigned long long)r4.w << 32) | r4.z;
+        {
+            const uint2 r2 = pa.rng[g][i];
+            rng.state = ((unsigned long long)r2.y << 32) | r2.x; rng.inc = rng_inc_of(rc, slot);
         }
         // ---- medium event (EXT): a real collision inside the homogeneous medium before the surface is reached?
         bool surface = true;                // false: the path ended or scattered in the medium
@@ -422,7 +443,6 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
         float sig_t[4] = {0.f, 0.f, 0.f, 0.f};
         if (EXT && rc.medium_on) {
             use_medium = true;
-            const float4 ro4 = pa.ray_o[slot];
             const f3 ro = mk3(ro4.x, ro4.y, ro4.z);
             float sig_a[4], sig_s[4];
 #pragma unroll
@@ -434,7 +454,6 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
             if (medium_segment(rc.med_bounds, ro, rd, prim_id == 0xFFFFFFFFu ? INFINITY : hv.y, &t0, &t1)) {
                 const float dlen = len3(rd), seg = (t1 - t0) * dlen;
                 const float u = rng_uniform(&rng), um = rng_uniform(&rng);
-                rng_dirty = true;
                 const float s = sig_t[0] > 0.0f ? -cr_log(1.0f - u) / sig_t[0] : INFINITY;
                 if (s < seg) {
                     surface = false;
@@ -467,10 +486,9 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
 #pragma unroll
                                                 for (int c = 0; c < 4; ++c) tr[c] = cr_exp(-sig_t[c] * sl);
                                             }
-                                            nt_store(pa.sh_o + slot, make_float4(p.x, p.y, p.z, 1.0f - 0.0001f));
-                                            nt_store(pa.sh_d + slot, make_float4(dir.x, dir.y, dir.z, 0.f));
-                                            nt_store(pa.sh_L + slot, make_float4(beta[0] * f * Ls.v[0] * tr[0] / den, beta[1] * f * Ls.v[1] * tr[1] / den,
-                                                                                 beta[2] * f * Ls.v[2] * tr[2] / den, beta[3] * f * Ls.v[3] * tr[3] / den));
+                                            s_o = make_float4(p.x, p.y, p.z, 1.0f - 0.0001f); s_d = dir;
+                                            s_L = make_float4(beta[0] * f * Ls.v[0] * tr[0] / den, beta[1] * f * Ls.v[1] * tr[1] / den,
+                                                              beta[2] * f * Ls.v[2] * tr[2] / den, beta[3] * f * Ls.v[3] * tr[3] / den);
                                             want_shadow = true;
                                         }
                                     }
@@ -480,10 +498,7 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                             float ppdf;
                             const f3 wi = sample_henyey_greenstein(wo, rc.med_g, u2, &ppdf);
                             if (ppdf != 0.0f && !(beta[0] == 0.0f && beta[1] == 0.0f && beta[2] == 0.0f && beta[3] == 0.0f)) {
-                                nt_store(pa.ray_o + slot, make_float4(p.x, p.y, p.z, 0.f));
-                                nt_store(pa.ray_d + slot, make_float4(wi.x, wi.y, wi.z, 0.f));
-                                nt_store(pa.beta + slot, make_float4(beta[0], beta[1], beta[2], beta[3]));
-                                nt_store(pa.misc + slot, make_uint2((uint32_t)depth, misc.y));      // specular_bounce = false
+                                c_o = p; c_d = wi; c_misc = (uint32_t)depth;      // specular_bounce = false
                                 cont = true;
                             }
                         }
@@ -511,10 +526,8 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
             // ---- interaction
             const uint32_t ref = sc.prim_ref[prim_id];
             SurfInt si;
-            if ((ref >> 30) == PM_PRIM_SPHERE) {
-                const float4 ro4 = pa.ray_o[slot];      // only the sphere's interaction needs the ray origin
-                si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], mk3(ro4.x, ro4.y, ro4.z), rd, hv.y);
-            } else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
+            if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], mk3(ro4.x, ro4.y, ro4.z), rd, hv.y);
+            else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
             // ---- emitted radiance of an area light on this primitive (simple_path.rs:156-158; EXT only)
             if (EXT && sc.prim_light && (!rc.sample_lights || specular)) {
                 const int li = sc.prim_light[prim_id];
@@ -531,11 +544,6 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
             depth++;
             Bsdf bsdf = make_bsdf(sc, pa, si, prim_id, lam, slot);
             const f3 wo = -rd;
-            if (!EXT) {
-                const uint4 r4 = pa.rng[slot];
-                rng.state = ((unsigned long long)r4.y << 32) | r4.x; rng.inc = ((unsigned long long)r4.w << 32) | r4.z;
-            }
-            rng_dirty = true;
             // ---- next-event estimation (simple_path.rs:182-213)
             if (rc.sample_lights) {
                 const float ul = rng_uniform(&rng);
@@ -563,14 +571,13 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) tr[c] = cr_exp(-sig_t[c] * sl);
                             }
-                            nt_store(pa.sh_o + slot, make_float4(so.x, so.y, so.z, 1.0f - 0.0001f));
-                            nt_store(pa.sh_d + slot, make_float4(dir.x, dir.y, dir.z, 0.f));
+                            s_o = make_float4(so.x, so.y, so.z, 1.0f - 0.0001f); s_d = dir;
                             if (EXT && use_medium)
-                                nt_store(pa.sh_L + slot, make_float4(beta[0] * f.v[0] * Ls.v[0] * tr[0] / den, beta[1] * f.v[1] * Ls.v[1] * tr[1] / den,
-                                                                     beta[2] * f.v[2] * Ls.v[2] * tr[2] / den, beta[3] * f.v[3] * Ls.v[3] * tr[3] / den));
+                                s_L = make_float4(beta[0] * f.v[0] * Ls.v[0] * tr[0] / den, beta[1] * f.v[1] * Ls.v[1] * tr[1] / den,
+                                                  beta[2] * f.v[2] * Ls.v[2] * tr[2] / den, beta[3] * f.v[3] * Ls.v[3] * tr[3] / den);
                             else
-                                nt_store(pa.sh_L + slot, make_float4(beta[0] * f.v[0] * Ls.v[0] / den, beta[1] * f.v[1] * Ls.v[1] / den,
-                                                                     beta[2] * f.v[2] * Ls.v[2] / den, beta[3] * f.v[3] * Ls.v[3] / den));
+                                s_L = make_float4(beta[0] * f.v[0] * Ls.v[0] / den, beta[1] * f.v[1] * Ls.v[1] / den,
+                                                  beta[2] * f.v[2] * Ls.v[2] / den, beta[3] * f.v[3] * Ls.v[3] / den);
                             want_shadow = true;
                         }
                     }
@@ -608,45 +615,56 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                 wi_next = wi; ok = true;
             }
             if (ok && !(beta[0] == 0.0f && beta[1] == 0.0f && beta[2] == 0.0f && beta[3] == 0.0f)) {
-                const f3 no = offset_ray_origin(si, wi_next);
-                nt_store(pa.ray_o + slot, make_float4(no.x, no.y, no.z, 0.f));
-                nt_store(pa.ray_d + slot, make_float4(wi_next.x, wi_next.y, wi_next.z, 0.f));
-                nt_store(pa.beta + slot, make_float4(beta[0], beta[1], beta[2], beta[3]));
-                nt_store(pa.misc + slot, make_uint2((uint32_t)depth | (specular ? 1u << 8 : 0u), misc.y));
+                c_o = offset_ray_origin(si, wi_next); c_d = wi_next;
+                c_misc = (uint32_t)depth | (specular ? 1u << 8 : 0u);
                 cont = true;
             }
             }
         }
-        if (rng_dirty) reinterpret_cast<uint2*>(pa.rng + slot)[0] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));   // inc never changes
     }
     uint32_t oi, si_;
     block_append2(cont, count_out, want_shadow, shadow_count, lds_ab, &oi, &si_);
-    if (cont) qout[oi] = slot;
-    if (want_shadow) pa.shq[si_] = slot;
+    if (cont) {         // the survivor's state, compacted: entry oi of the next queue, generation g ^ 1
+        const uint32_t h = g ^ 1u;
+        nt_store(pa.ro[h] + oi, with_w(c_o, slot));
+        nt_store(pa.rd[h] + oi, with_w(c_d, c_misc));
+        nt_store(pa.beta[h] + oi, make_float4(beta[0], beta[1], beta[2], beta[3]));
+        nt_store(pa.lambda[h] + oi, l4);
+        nt_store(pa.rng[h] + oi, make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32)));
+    }
+    if (want_shadow) {
+        nt_store(pa.sh_o + si_, s_o);
+        nt_store(pa.sh_d + si_, with_w(s_d, slot));
+        nt_store(pa.sh_L + si_, s_L);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ shade (RandomWalk)
 // RandomWalkIntegrator::incident_radiance_random_walk (integrators/random_walk.rs:106-173), recursion unrolled: bounce d
 // stores f * |cos| in rw_f[d]; when the walk ends with radiance Le, the result is folded from the deepest bounce outwards
 // exactly as the recursion returns it:  L = 0 + f_d * L / (1 / (4 pi)).
-__global__ __launch_bounds__(RB) void shade_rw_kernel(RenderConst rc, SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ qin,
-                                                      const uint32_t* __restrict__ count_in, uint32_t* __restrict__ qout,
-                                                      uint32_t* __restrict__ count_out) {
+__global__ __launch_bounds__(RB) void shade_rw_kernel(RenderConst rc, SceneArrays sc, PathArrays pa, uint32_t g,
+                                                      const uint32_t* __restrict__ count_in, uint32_t* __restrict__ count_out) {
     __shared__ uint32_t lds_a[RB / 64 + 1];
     const uint32_t i = blockIdx.x * RB + threadIdx.x;
     const uint32_t n_in = *count_in;
     if (blockIdx.x * RB >= n_in) return;             // whole block idle (uniform exit, before any barrier)
     bool cont = false;
-    uint32_t slot = 0;
+    uint32_t slot = 0, c_misc = 0;
+    f3 c_o = mk3(0.f, 0.f, 0.f), c_d = mk3(0.f, 0.f, 0.f);
+    float4 l4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    Rng rng; rng.state = 0ull; rng.inc = 0ull;
     const bool live = i < n_in;
-    if (live) slot = qin[i];
-    const uint2 misc = live ? pa.misc[slot] : make_uint2(0xFFFFFFFFu, 0u);
-    if (live && misc.x != 0xFFFFFFFFu) {
-        const float4 hv = pa.hit[slot];
+    const float4 rd4 = live ? pa.rd[g][i] : make_float4(0.f, 0.f, 0.f, __uint_as_float(PM_DEAD));
+    const uint32_t mw = __float_as_uint(rd4.w);
+    if (live && mw != PM_DEAD) {
+        const float4 ro4 = pa.ro[g][i];
+        slot = __float_as_uint(ro4.w);
+        const float4 hv = pa.hit[i];
         const uint32_t prim_id = __float_as_uint(hv.x);
-        const float4 l4 = pa.lambda[slot];
+        l4 = pa.lambda[g][i];
         const float lam[4] = {l4.x, l4.y, l4.z, l4.w};
-        const int depth = (int)(misc.x & 0xFFu);
+        const int depth = (int)(mw & 0xFFu);
         float Lr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         bool done = true;
         if (prim_id == 0xFFFFFFFFu) {
@@ -656,7 +674,6 @@ __global__ __launch_bounds__(RB) void shade_rw_kernel(RenderConst rc, SceneArray
                 for (int c = 0; c < 4; ++c) Lr[c] += le.v[c];
             }
         } else if (depth != rc.max_depth) {
-            const float4 ro4 = pa.ray_o[slot], rd4 = pa.ray_d[slot];
             const f3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
             const uint32_t ref = sc.prim_ref[prim_id];
             SurfInt si;
@@ -664,10 +681,9 @@ __global__ __launch_bounds__(RB) void shade_rw_kernel(RenderConst rc, SceneArray
             else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
             const Bsdf bsdf = make_bsdf(sc, pa, si, prim_id, lam, slot);
             const f3 wo = -rd;
-            const uint4 r4 = pa.rng[slot];
-            Rng rng; rng.state = ((unsigned long long)r4.y << 32) | r4.x; rng.inc = ((unsigned long long)r4.w << 32) | r4.z;
+            const uint2 r2 = pa.rng[g][i];
+            rng.state = ((unsigned long long)r2.y << 32) | r2.x; rng.inc = rng_inc_of(rc, slot);
             f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
-            reinterpret_cast<uint2*>(pa.rng + slot)[0] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));   // inc never changes
             const f3 wp = sample_uniform_sphere(u2);
             Spec4 f = bsdf_eval(bsdf, wo, wp);
             if (!spec_zero(f)) {
@@ -675,10 +691,7 @@ __global__ __launch_bounds__(RB) void shade_rw_kernel(RenderConst rc, SceneArray
 #pragma unroll
                 for (int c = 0; c < 4; ++c) f.v[c] *= ad;
                 pa.rw_f[(size_t)depth * pa.cap + slot] = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
-                const f3 no = offset_ray_origin(si, wp);
-                pa.ray_o[slot] = make_float4(no.x, no.y, no.z, 0.f);
-                pa.ray_d[slot] = make_float4(wp.x, wp.y, wp.z, 0.f);
-                pa.misc[slot] = make_uint2((uint32_t)(depth + 1), misc.y);
+                c_o = offset_ray_origin(si, wp); c_d = wp; c_misc = (uint32_t)(depth + 1);
                 cont = true; done = false;
             }
         }
@@ -693,7 +706,13 @@ __global__ __launch_bounds__(RB) void shade_rw_kernel(RenderConst rc, SceneArray
         }
     }
     const uint32_t oi = block_append(cont, count_out, lds_a);
-    if (cont) qout[oi] = slot;
+    if (cont) {
+        const uint32_t h = g ^ 1u;
+        pa.ro[h][oi] = with_w(c_o, slot);
+        pa.rd[h][oi] = with_w(c_d, c_misc);
+        pa.lambda[h][oi] = l4;
+        pa.rng[h][oi] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+    }
 }
 
 // ------------------------------------------------------------------------------------------ accumulate
@@ -706,9 +725,9 @@ __global__ __launch_bounds__(RB) void accumulate_kernel(RenderConst rc, SceneArr
     double acc[4] = {fp[0], fp[1], fp[2], fp[3]};
     for (int s = 0; s < rc.s_count; ++s) {
         const uint32_t slot = (uint32_t)s * (uint32_t)rc.npix_pad + p;
-        const float4 L4 = pa.L[slot], l4 = pa.lambda[slot], p4 = pa.pdf[slot];
+        const float4 L4 = pa.L[slot], l4 = pa.lambda_s[slot], p4 = pa.pdf[slot];
         const float L[4] = {L4.x, L4.y, L4.z, L4.w}, lam[4] = {l4.x, l4.y, l4.z, l4.w}, pd[4] = {p4.x, p4.y, p4.z, p4.w};
-        const float w = __uint_as_float(pa.misc[slot].y);
+        const float w = pa.fw[slot];
         float Lp[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) Lp[i] = pd[i] != 0.0f ? (L[i] * 1.0f) / pd[i] : 0.0f;
@@ -1030,15 +1049,14 @@ static int ensure_paths(pm_ctx* c, RenderState* r, size_t npaths, int max_depth,
     r->pa_allocs.clear(); r->pa_cap = 0;
     auto al = [&](void** p, size_t bytes) -> int { HIPCHK(c, hipMalloc(p, bytes)); r->pa_allocs.push_back(*p); return PM_OK; };
     PathArrays& pa = r->pa;
-    float4** f4[] = {&pa.ray_o, &pa.ray_d, &pa.beta, &pa.L, &pa.lambda, &pa.pdf, &pa.hit, &pa.sh_o, &pa.sh_d, &pa.sh_L};
+    float4** f4[] = {&pa.ro[0], &pa.ro[1], &pa.rd[0], &pa.rd[1], &pa.beta[0], &pa.beta[1], &pa.lambda[0], &pa.lambda[1],
+                     &pa.hit, &pa.sh_o, &pa.sh_d, &pa.sh_L, &pa.L, &pa.lambda_s, &pa.pdf};
     int rc;
     for (auto p : f4) if ((rc = al((void**)p, npaths * sizeof(float4)))) return rc;
-    if ((rc = al((void**)&pa.rng, npaths * sizeof(uint4)))) return rc;
-    if ((rc = al((void**)&pa.misc, npaths * sizeof(uint2)))) return rc;
-    if ((rc = al((void**)&pa.q0, npaths * 4))) return rc;
-    if ((rc = al((void**)&pa.q1, npaths * 4))) return rc;
-    if ((rc = al((void**)&pa.shq, npaths * 4))) return rc;
-    if ((rc = al((void**)&pa.counts, 2 * (size_t)(max_depth + 2) * 4))) return rc;
+    if ((rc = al((void**)&pa.rng[0], npaths * sizeof(uint2)))) return rc;
+    if ((rc = al((void**)&pa.rng[1], npaths * sizeof(uint2)))) return rc;
+    if ((rc = al((void**)&pa.fw, npaths * sizeof(float)))) return rc;
+    if ((rc = al((void**)&pa.counts, 2 * (size_t)(max_depth + 2) * 4 * PM_CNT_STRIDE))) return rc;
     pa.rw_f = nullptr; pa.cap = (uint32_t)npaths;
     if (random_walk && (rc = al((void**)&pa.rw_f, (size_t)std::max(1, max_depth) * npaths * sizeof(float4)))) return rc;
     r->pa_cap = npaths; r->pa_depth = max_depth;
@@ -1064,7 +1082,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     int rcode;
     if (r->scene_dirty || r->geom_gen != c->geom_gen) if ((rcode = upload_scene(c, r))) return rcode;
     r->stats = PmRenderStats{};
-    r->stats.state_bytes_per_path = 10 * 16 + 16 + 8 + 12;
+    r->stats.state_bytes_per_path = PM_PATH_BYTES;
     const int W = x1 - x0, H = y1 - y0;
     if (W == 0 || H == 0 || s0 == s1) return PM_OK;
     const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
@@ -1078,8 +1096,8 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     {   // ... but never more than half of the memory that is free on the device now (another process may share it)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t held = r->pa_cap * (size_t)(10 * 16 + 16 + 8 + 12);         // what ensure_paths would free first
-            const size_t per_path = 10 * 16 + 16 + 8 + 12 + 16 + 4 + (p->integrator == PM_INTEGRATOR_RANDOM_WALK ? (size_t)std::max(1, p->max_depth) * 16 : 0);
+            const size_t held = r->pa_cap * (size_t)PM_PATH_BYTES;         // what ensure_paths would free first
+            const size_t per_path = PM_PATH_BYTES + 16 + 4 + (p->integrator == PM_INTEGRATOR_RANDOM_WALK ? (size_t)std::max(1, p->max_depth) * 16 : 0);
             target = std::min(target, std::max<size_t>((size_t)1 << 16, (free_b + held) / 2 / per_path));
         }
     }
@@ -1117,7 +1135,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
                    r->have_area_lights ? r->d_prim_light : nullptr};
     PathArrays& pa = r->pa;
     const int nb = p->max_depth + 2;
-    std::vector<uint32_t> hcounts(2 * (size_t)nb);
+    std::vector<uint32_t> hcounts(2 * (size_t)nb * PM_CNT_STRIDE);
     const size_t max_launch = 3 * (size_t)(p->max_depth + 1) + 3;
     while (r->ev_pool.size() < max_launch + 1) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); r->ev_pool.push_back(e); }
     std::vector<int> ev_class; ev_class.reserve(max_launch);
@@ -1129,7 +1147,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
         ev_class.clear();
         rc.s_base = sb; rc.s_count = std::min(s_per_pass, s1 - sb);
         const uint32_t npaths = (uint32_t)(npix_pad * (size_t)rc.s_count);
-        HIPCHK(c, hipMemsetAsync(pa.counts, 0, 2 * (size_t)nb * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(pa.counts, 0, 2 * (size_t)nb * 4 * PM_CNT_STRIDE, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_work, 0, 3 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
         int wslot = 0;      // one work counter per traversal launch (re-zeroed when the slots run out)
         const dim3 gr((npaths + RB - 1) / RB);
@@ -1138,9 +1156,10 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
         const bool flat = c->flat.tris != nullptr, fpatch = c->flat.n_patch > 0;
         mark(0);
         hipLaunchKernelGGL(raygen_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, npaths);
-        uint32_t *qin = pa.q0, *qout = pa.q1;
+        uint32_t gen = 0;       // generation of the path-state arrays that holds the current queue
         for (int b = 0; b <= p->max_depth; ++b) {
-            uint32_t* cnt_in = pa.counts + b; uint32_t* cnt_out = pa.counts + b + 1; uint32_t* cnt_sh = pa.counts + nb + b;
+            uint32_t* cnt_in = pa.counts + (size_t)b * PM_CNT_STRIDE; uint32_t* cnt_out = pa.counts + (size_t)(b + 1) * PM_CNT_STRIDE;
+            uint32_t* cnt_sh = pa.counts + (size_t)(nb + b) * PM_CNT_STRIDE;
             if (wslot + 2 > PM_WORK_SLOTS) {   // stream-ordered: every earlier traversal kernel has finished with its counter
                 HIPCHK(c, hipMemsetAsync(c->d_work, 0, 3 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
                 wslot = 0;
@@ -1149,21 +1168,21 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
             if (flat) {
                 auto kernel = c->counting ? (fpatch ? closest_flat_kernel<true, true> : closest_flat_kernel<true, false>)
                                           : (fpatch ? closest_flat_kernel<false, true> : closest_flat_kernel<false, false>);
-                hipLaunchKernelGGL(kernel, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, qin, cnt_in, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, c->d_slow, c->d_counters);
+                hipLaunchKernelGGL(kernel, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, gen, cnt_in, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, c->d_slow, c->d_counters);
             } else {
                 auto kernel = c->counting ? (mixed ? closest_kernel<true, true> : closest_kernel<true, false>)
                                           : (mixed ? closest_kernel<false, true> : closest_kernel<false, false>);
-                hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, qin, cnt_in, c->d_work + wslot, c->refill, c->d_defer, (uint32_t)c->defer_cap, c->d_counters);
+                hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, gen, cnt_in, c->d_work + wslot, c->refill, c->d_defer, (uint32_t)c->defer_cap, c->d_counters);
             }
             if (has_spheres || flat) {     // second pass: dense exact tests of what was deferred (timed with the closest-hit class)
-                if (c->counting) hipLaunchKernelGGL(closest_fix_kernel<true>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, qin, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
-                else hipLaunchKernelGGL(closest_fix_kernel<false>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, qin, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
+                if (c->counting) hipLaunchKernelGGL(closest_fix_kernel<true>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, gen, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
+                else hipLaunchKernelGGL(closest_fix_kernel<false>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, gen, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
             }
             ++wslot;
             mark(2);
-            if (random_walk) hipLaunchKernelGGL(shade_rw_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, qin, cnt_in, qout, cnt_out);
-            else if (shade_ext) hipLaunchKernelGGL(shade_kernel<true>, gr, dim3(RB), 0, c->stream, rc, sa, pa, qin, cnt_in, qout, cnt_out, cnt_sh);
-            else hipLaunchKernelGGL(shade_kernel<false>, gr, dim3(RB), 0, c->stream, rc, sa, pa, qin, cnt_in, qout, cnt_out, cnt_sh);
+            if (random_walk) hipLaunchKernelGGL(shade_rw_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out);
+            else if (shade_ext) hipLaunchKernelGGL(shade_kernel<true>, gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out, cnt_sh);
+            else hipLaunchKernelGGL(shade_kernel<false>, gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out, cnt_sh);
             if (!random_walk && p->sample_lights && b < p->max_depth) {
                 mark(3);
                 if (flat) {
@@ -1181,7 +1200,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
                 }
                 ++wslot;
             }
-            std::swap(qin, qout);
+            gen ^= 1u;
             r->stats.kernels_launched += 3;
         }
         if (!debug_one) mark(4);
@@ -1201,8 +1220,8 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
         r->stats.samples += (uint64_t)W * H * rc.s_count;
         // closest rays: every live path in the queue of bounce b (padded slots are not live)
         const uint64_t pad = (uint64_t)(npix_pad - (size_t)W * H) * rc.s_count;
-        for (int b = 0; b <= p->max_depth; ++b) r->stats.closest_rays += hcounts[b] - (b == 0 ? pad : 0);
-        for (int b = 0; b < nb; ++b) r->stats.shadow_rays += hcounts[nb + b];
+        for (int b = 0; b <= p->max_depth; ++b) r->stats.closest_rays += hcounts[(size_t)b * PM_CNT_STRIDE] - (b == 0 ? pad : 0);
+        for (int b = 0; b < nb; ++b) r->stats.shadow_rays += hcounts[(size_t)(nb + b) * PM_CNT_STRIDE];
     }
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1218,13 +1237,13 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
         if (cnt_after[3] != cnt_before[3]) return fail(c, PM_ERR_STACK_OVERFLOW, "pm_render: traversal stack overflow");
     }
     if (debug_one) {
-        float4 h[3]; uint2 m;
+        float4 h[3]; float fwv;
         HIPCHK(c, hipMemcpy(&h[0], pa.L, 16, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(&h[1], pa.lambda, 16, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&h[1], pa.lambda_s, 16, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(&h[2], pa.pdf, 16, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(&m, pa.misc, 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&fwv, pa.fw, 4, hipMemcpyDeviceToHost));
         std::memcpy(out13, h, 48);
-        std::memcpy(out13 + 12, &m.y, 4);
+        std::memcpy(out13 + 12, &fwv, 4);
     }
     return PM_OK;
 }

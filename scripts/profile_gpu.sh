@@ -20,6 +20,8 @@ for W in path trace; do
   timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d $OUT/pmc_write_$W -o w --output-format csv -- python3 bench.py $ARGS > $OUT/pmc_write_$W.log 2>&1 || exit 1
   step pmc-sq-$W
   timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $OUT/pmc_sq_$W -o s --output-format csv -- python3 bench.py $ARGS > $OUT/pmc_sq_$W.log 2>&1 || exit 1
+  step pmc-lanes-$W
+  timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_lanes_$W -o l --output-format csv -- python3 bench.py $ARGS > $OUT/pmc_lanes_$W.log 2>&1 || exit 1
 done
 step done
 ls -R $OUT | head -60 >> $OUT/progress.log
