@@ -7,19 +7,37 @@ torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
 Workloads (BASELINE.json configs):
   path    C2 (default, BASELINE.json configs[1]): Cornell box, SimplePathIntegrator(max_depth 5, NEE, BSDF sampling),
           1024x1024 @ 64 spp per GPU.  A step = one whole Integrate::render() of the image plus — for N>1 — the
-          film merge.  Metric: path samples/s.  N>1: sample split (rank r renders sample indices [64r, 64(r+1)) of a
-          64*N-spp image), films merged by ONE RCCL all-reduce of the f64 film per step => weak scaling.
-          The C3 closest-hit figure is measured in the same run and reported under "closest_hit".
-  trace   C3: 1,048,576-triangle synthetic mesh, 4096x4096 primary rays per GPU, closest hit.  Metric: Mrays/s.
-          Rays shard across ranks with no collective (every rank owns a replica of the BVH) => weak scaling.
+          film merge.  Metric: path samples/s (`value`).  The default run ALSO measures, each under its own key and each
+          with its own roofline and CPU baseline (N=1 only; not `value`):
+            closest_hit   C3: 1,048,576-triangle mesh, 4096x4096 primary rays (+ shadow and incoherent ray sets)
+            c4_path       C4 scene (20,971,520 triangles under a uniform sky, device-built BVH), 3840x2160 @ 8 spp = one
+                          pass of 2^26 paths through the wide-BVH walk
+            c5_path       C5: Cornell box + quad area light + homogeneous medium, VolPath depth 16, 1024x1024 @ 8 spp,
+                          with the queue occupancy per bounce
+  trace   C3 alone.  Metric: Mrays/s.  Rays shard across ranks with no collective => weak scaling.
+  c4      C4 at full size (3840x2160 @ 256 spp).  --scaling strong splits the 256 spp across the ranks (BASELINE's
+          8-GPU configuration: 32 spp per GPU); --merge rows splits the image rows instead and all-gathers the bands.
+  c5      C5 alone.
+Scaling: weak by default (per-GPU work fixed: rank r renders sample indices [spp*r, spp*(r+1)) of an N*spp image);
+`--scaling strong` fixes the total work.  Films are merged by ONE RCCL all-reduce (or all-gather for --merge rows) per step.
 Inputs (scene, BVH, rays) are resident in HBM before the timed region starts.
 
-The oracle (oracle/) is used ONLY for the cpu_baseline leg, on rank 0 at N=1.
+Roofline.  `roofline.achieved` = algorithmic HBM bytes of the dominant kernel per launch / its mean launch duration (HIP
+events on the library's stream, measured live).  Algorithmic bytes = path state, rays and hits the kernel must move, plus
+the BVH nodes and leaf records its rays fetch (SURVEY 8d demand counters) ONLY when the scene exceeds the 256 MB Infinity
+Cache — a resident scene (C2: 2.5 KB, C3: 126 MB) costs no HBM traffic, and charging it made round 1's fractions
+meaningless; the demand figure is still reported as `demand_GBps`.  `roofline.traffic` = HBM-side bytes per launch of the
+same kernel from the committed rocprofv3 --pmc passes (profiles/rNN/pmc_summary_*.json).  The traversal kernels are bound by
+VALU issue, not HBM: `roofline.issue` carries their issue-rate fraction and active-lane fraction from the same passes.
+
+The oracle (oracle/) is used ONLY for the cpu_baseline legs, on rank 0 at N=1.
 """
 import argparse
+import glob
 import importlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -29,31 +47,40 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+L3_BYTES = 256e6        # Infinity Cache: a scene below this stays on-die between launches
 KERNEL_NAMES = ["raygen_kernel", "closest_kernel", "shade_kernel", "shadow_kernel", "accumulate_kernel"]
+# timed (non-counting) variants as rocprofv3 names them
+PMC_NAME = {"raygen_kernel": r"^raygen_kernel", "closest_kernel": r"^closest(_flat)?_kernel<false", "shade_kernel": r"^shade_kernel",
+            "shadow_kernel": r"^shadow(_flat)?_kernel<false", "accumulate_kernel": r"^accumulate_kernel"}
 
 
-def pmc_traffic(kernel_regex, tag):
-    """HBM bytes per launch of the kernel whose name matches `kernel_regex`, from the committed rocprofv3 --pmc passes of
-    this same command (profiles/rNN/pmc_summary_<tag>.json, made by scripts/profile_gpu.sh + scripts/summarize_pmc.py):
-    FETCH_SIZE doubled for wide loads as MI355X_MICROARCH.md prescribes, plus WRITE_SIZE.  None when no summary is
-    committed.  The newest round's summary that holds the kernel wins."""
-    import glob
-    import re
+def pmc_entry(kernel_regex, tag):
+    """the committed PMC summary (scripts/profile_gpu.sh + scripts/summarize_pmc.py) of the kernel matching `kernel_regex`
+    in profiles/rNN/pmc_summary_<tag>.json; the newest round that holds the kernel wins.  (entry, path) or (None, None)."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_summary_{tag}.json")), reverse=True):
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
         for name, v in d.items():
-            if re.search(kernel_regex, name) and "fetch_bytes_x2_wide_loads" in v and "write_bytes" in v:
-                return (v["fetch_bytes_x2_wide_loads"] + v["write_bytes"]) / max(1, v["dispatches"]), os.path.relpath(path, ROOT)
+            if re.search(kernel_regex, name):
+                return v, os.path.relpath(path, ROOT)
     return None, None
 
 
-# timed (non-counting) variants of the kernel classes, as rocprofv3 names them: the first template argument of the
-# render kernels (COUNT) and the second of trace_kernel / trace_flat_kernel is false
-PMC_NAME = {"raygen_kernel": r"^raygen_kernel", "closest_kernel": r"^closest(_flat)?_kernel<false", "shade_kernel": r"^shade_kernel",
-            "shadow_kernel": r"^shadow(_flat)?_kernel<false", "accumulate_kernel": r"^accumulate_kernel"}
+def pmc_fields(kernel_regex, tag):
+    """roofline fields that come from the committed counters: HBM-side traffic per launch and the issue-side figures"""
+    v, src = pmc_entry(kernel_regex, tag)
+    if v is None:
+        return {"traffic": None, "traffic_source": None}
+    out = {"traffic": (v["fetch_bytes_x2_wide_loads"] + v["write_bytes"]) if "fetch_bytes_x2_wide_loads" in v and "write_bytes" in v else None,
+           "traffic_source": src}
+    if "valu_issue_frac" in v:
+        out["issue"] = {"bound": "valu_issue", "frac": v["valu_issue_frac"], "active_lane_frac": v.get("active_lane_frac"),
+                        "wait_frac": v.get("wait_frac"), "l2_hit_rate": v.get("l2_hit_rate"),
+                        "definition": "SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); lanes = "
+                                      "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64", "source": src}
+    return out
 
 
 def parse():
@@ -61,27 +88,38 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="path", choices=["path", "trace", "c4"])
+    ap.add_argument("--workload", default="path", choices=["path", "trace", "c4", "c5"])
     ap.add_argument("--res", type=int, default=None, help="image side (path: 1024, trace: 4096)")
-    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per GPU (path workload)")
-    ap.add_argument("--max-depth", type=int, default=5)
-    ap.add_argument("--blobs", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=None, help="samples per pixel per GPU (weak) or in total (strong)")
+    ap.add_argument("--max-depth", type=int, default=None)
+    ap.add_argument("--blobs", type=int, default=None)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--merge", default="samples", choices=["samples", "rows"],
+                    help="N>1: split sample indices and all-reduce the film (default) or split rows and all-gather the bands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="path workload: skip the C3 closest-hit figure")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="rays in the bounded CPU-baseline sample (trace; about 20 core-seconds)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time bound (path)")
+    ap.add_argument("--no-secondary", action="store_true", help="path workload: only the C2 leg")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="rays in the bounded CPU-baseline sample (trace)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time bound per path leg")
     ap.add_argument("--max-leaf", type=int, default=4, help="max_prims_in_node of BVHAggregate::new (wide leaves hold <= 4)")
-    ap.add_argument("--split", default="sah", choices=["sah", "hlbvh"],
-                    help="BVH build: binned SAH on the host (default) or the linear BVH built on the device (triangle scenes)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse "
-                                                       "several ranks on one GPU)")
+    ap.add_argument("--split", default=None, choices=["sah", "hlbvh"],
+                    help="BVH build: binned SAH on the host or the linear BVH built on the device (default: hlbvh for C4, sah otherwise)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     return ap.parse_args()
+
+
+def note(msg):
+    """progress on stderr (stdout carries only the JSON line)"""
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
 def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as ora
     return ora
+
+
+def cpu_threads():
+    return min(16, len(os.sched_getaffinity(0)))
 
 
 def cpu_baseline_trace(pos, idx, rays_sample, threads):
@@ -102,30 +140,34 @@ def cpu_baseline_trace(pos, idx, rays_sample, threads):
             "nodes_per_ray": ctr["nodes_visited"] / len(rays_sample), "prims_per_ray": ctr["prims_tested"] / len(rays_sample)}
 
 
-def cpu_baseline_path(pm, sd, spp, max_depth, threads, seconds):
+def cpu_baseline_path(pm, sd, spp, max_depth, threads, seconds, integrator=None, rows=None):
     """The oracle's Integrate::render() (row-parallel like the reference's rayon loop, base.rs:50-63) on a bounded
-    sample of the same workload: the same image, one sample index (one sample of every pixel) at a time, until
+    sample of the same workload: the same image (or the row band `rows` of it), one sample index at a time, until
     `seconds` have elapsed."""
     ora = _oracle()
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers
+    t0 = time.time()
     oren = helpers.oracle_renderer_from(sd, ora)
+    build_s = time.time() - t0
     x0, y0, x1, y1 = sd.film["pixel_bounds"]
-    band = (x0, y0, x1, y1)
+    band = (x0, rows[0], x1, rows[1]) if rows else (x0, y0, x1, y1)
     n, s, t0 = 0, 0, time.time()
     while s < spp and time.time() - t0 < seconds:
-        p = helpers.render_params(pm, sd, spp, max_depth, True, True, 0, window=band, samples=(s, s + 1))
+        p = helpers.render_params(pm, sd, spp, max_depth, True, True, 0, window=band, samples=(s, s + 1), integrator=integrator)
         n += oren.render(p, threads)["samples"]
         s += 1
     dt = time.time() - t0
     return {"value": n / dt, "unit": "samples/s", "cores": threads, "kind": "port",
             "sample": f"rows {band[1]}..{band[3]} of the same {x1 - x0}x{y1 - y0} image, sample indices 0..{s} "
-                      f"({n} path samples, {dt:.1f} s)"}
+                      f"({n} path samples, {dt:.1f} s; reference-layout binary BVH built in {build_s:.1f} s, not included)"}
 
 
-def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, want_cpu):
-    res = args.res or 4096
-    pos, idx = pm.scenes.blob_mesh(args.blobs, 1024, seed=1)
+# ------------------------------------------------------------------------------------------------ C3
+def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, want_cpu, secondary=True):
+    res = args.res if (args.res and args.workload == "trace") else 4096
+    blobs = args.blobs if (args.blobs and args.workload == "trace") else 1024
+    pos, idx = pm.scenes.blob_mesh(blobs, 1024, seed=1)
     split = pm._capi.PM_SPLIT_HLBVH if args.split == "hlbvh" else pm._capi.PM_SPLIT_SAH
     agg = pm.GpuAggregate([pm.TriangleMesh(pos, idx)], max_prims_in_node=args.max_leaf, device_id=local_rank, split_method=split)
     rays = pm.scenes.primary_rays(res, res, eye=(0.02 * rank, 0.0, -4.0))
@@ -133,7 +175,7 @@ def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, wan
     d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
     d_hits = torch.empty((n_rays, 4), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
-    # deterministic traversal counters (untimed pass with the counting kernel) -> algorithmic bytes
+    # deterministic traversal counters (untimed pass with the counting kernel) -> demand bytes
     agg.set_counting(True)
     agg.reset_counters()
     agg.intersect(d_rays, out=d_hits)
@@ -141,7 +183,12 @@ def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, wan
     agg.set_counting(False)
     n_node, n_prim = ctr["nodes_visited"] / n_rays, ctr["prims_tested"] / n_rays
     s_node, s_prim = agg.info.node_bytes, agg.info.prim_record_bytes[2]
-    bytes_per_ray = 32 + 16 + n_node * s_node + n_prim * s_prim
+    scene_bytes = agg.info.node_buffer_bytes + agg.info.prim_buffer_bytes
+    resident = scene_bytes < L3_BYTES
+
+    def bytes_per_ray(nn, npr, out_bytes):
+        demand = 32 + out_bytes + nn * s_node + npr * s_prim
+        return (32 + out_bytes) if resident else demand, demand
 
     def barrier():
         if world > 1:
@@ -164,26 +211,30 @@ def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, wan
         dt = float(t.item())
     hit_frac = float((d_hits[:, 0].view(torch.int32) != -1).float().mean().item())
     k_ms = float(np.mean(kernel_ms))
-    achieved = bytes_per_ray * n_rays / (k_ms * 1e-3) / 1e9
+    bpr, demand = bytes_per_ray(n_node, n_prim, 16)
+    achieved = bpr * n_rays / (k_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "kernel": "trace_kernel<false,false,false>", "kernel_ms": k_ms, "bytes_per_ray": bpr,
+            "demand_GBps": demand * n_rays / (k_ms * 1e-3) / 1e9, "demand_bytes_per_ray": demand,
+            "nodes_per_ray": n_node, "prims_per_ray": n_prim, "scene_bytes": int(scene_bytes),
+            "note": ("the %.0f MB scene (nodes + leaf records) stays in the 256 MB Infinity Cache, so the algorithmic HBM bytes are "
+                     "the rays and hits alone; the kernel is bound by VALU issue (`issue`), not by HBM" % (scene_bytes / 1e6))
+                    if resident else "scene larger than the Infinity Cache: node / record fetches count as HBM bytes (demand)"}
+    roof.update(pmc_fields(r"^trace(_flat)?_kernel<false, false", "trace"))
     out = {
         "metric": "closest-hit Mrays/s", "value": n_rays * world * steps / dt / 1e6, "unit": "Mrays/s", "n_gpus": world,
         "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"C3 closest-hit microbench: {len(idx)} triangles ({args.blobs} blobs x 1024), "
+        "config": {"workload": f"C3 closest-hit microbench: {len(idx)} triangles ({blobs} blobs x 1024), "
                                f"{res}x{res} primary rays per GPU in 8x8 tile order",
                    "rays_per_gpu": n_rays, "hit_fraction": hit_frac, "bvh_nodes": int(agg.info.n_nodes),
-                   "bvh_build": args.split, "bvh_build_seconds": float(agg.info.build_seconds),
-                   "bvh_node_bytes": int(s_node), "tri_record_bytes": int(s_prim)},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(r"^trace(_flat)?_kernel<false, false", "trace")[0],
-                     "traffic_source": pmc_traffic(r"^trace(_flat)?_kernel<false, false", "trace")[1],
-                     "kernel": "trace_kernel<false,false>", "kernel_ms": k_ms,
-                     "bytes_per_ray": bytes_per_ray, "nodes_per_ray": n_node, "prims_per_ray": n_prim,
-                     "note": "achieved = DEMAND bytes (every node / record fetch of the walk counted as a miss, SURVEY 8d) per "
-                             "second; this tree fits the L2s + Infinity Cache, so the HBM side moves far less (traffic = PMC "
-                             "bytes per launch) and the kernel is bound by instruction issue, not by HBM"},
+                   "bvh_build": args.split or "sah", "bvh_build_seconds": float(agg.info.build_seconds),
+                   "bvh_node_bytes": int(s_node), "tri_record_bytes": int(s_prim),
+                   "generator": "numpy PCG64 (default_rng), blob sigma 0.06 (SURVEY 8d says PCG32 streams and 0.02: the tighter "
+                                "blobs leave most primary rays without a hit)"},
+        "roofline": roof,
     }
-    if not args.no_secondary:
+    if secondary:
         # SURVEY.md 8(d) C3's other two ray sets, each with its own counters and event-timed launches (not `value`)
         hits_host = np.empty(n_rays, dtype=pm.HIT_DTYPE)
         hits_host.view(np.float32).reshape(-1, 4)[:] = d_hits.cpu().numpy()
@@ -213,82 +264,105 @@ def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, wan
             ms = float(np.mean(ms))
             live = int((rset["tmax"] > 0).sum())
             nn, npr = c2["nodes_visited"] / n_rays, c2["prims_tested"] / n_rays
-            bpr = 32 + (1 if any_hit else 16) + nn * s_node + npr * s_prim
-            ach = bpr * n_rays / (ms * 1e-3) / 1e9
+            b, dem = bytes_per_ray(nn, npr, 1 if any_hit else 16)
+            ach = b * n_rays / (ms * 1e-3) / 1e9
             frac_out = (float(d_o.float().mean().item()) if any_hit
                         else float((d_o[:, 0].view(torch.int32) != -1).float().mean().item()))
             out[key] = {"value": n_rays / (ms * 1e-3) / 1e6, "unit": "Mrays/s (this GPU, event-timed kernel)", "rays": what,
                         "kernel_ms": ms, "live_rays": live, "occluded_or_hit_fraction": frac_out,
                         "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": ach / HBM_PEAK_GBS, "bytes_per_ray": bpr, "nodes_per_ray": nn,
-                                     "prims_per_ray": npr, "fallback_walks": c2["fallback_walks"]}}
+                                     "frac": ach / HBM_PEAK_GBS, "bytes_per_ray": b, "demand_GBps": dem * n_rays / (ms * 1e-3) / 1e9,
+                                     "nodes_per_ray": nn, "prims_per_ray": npr, "fallback_walks": c2["fallback_walks"]}}
             del d_r, d_o
     if want_cpu and rank == 0:
-        threads = min(16, len(os.sched_getaffinity(0)))
-        out["cpu_baseline"] = cpu_baseline_trace(pos, idx, rays[:args.cpu_sample], threads)
-    del agg
+        note("C3 cpu baseline")
+        out["cpu_baseline"] = cpu_baseline_trace(pos, idx, rays[:args.cpu_sample], cpu_threads())
+    agg.close()
     return out
 
 
-def kernel_bytes(st, info, sd):
-    """Algorithmic HBM bytes of one render() per kernel class: structure-of-arrays path state that each
-    kernel must read/write once per item + the scene data its rays need.  Tree walk: BVH node / leaf-record bytes from
-    the traversal counters (demand traffic, every fetch counted).  Flat sweep (scenes of <= 64 primitives): the flat table
-    is read once per WAVE of 64 rays through scalar loads, so a ray's share is 1/64 of the entries it was offered, plus
-    the 48..80-byte record of every exact test it ran (those are per-lane loads)."""
+# ------------------------------------------------------------------------------------------------ path tracing
+def kernel_bytes(st, info, spp_rendered, ext):
+    """Algorithmic HBM bytes of one render() per kernel class: the path state each kernel must read and
+    write per queue entry (dense, pm_render.hip PathArrays) + - for scenes that do not fit the Infinity Cache - the BVH
+    nodes and leaf records its rays fetch (demand counters).  Returns (bytes, demand_bytes)."""
     rec = info.prim_buffer_bytes / max(1, info.n_prims)     # mean leaf-record size of this scene
     node = info.node_bytes
+    resident = (info.node_buffer_bytes + info.prim_buffer_bytes) < L3_BYTES
     S, C, SH = st["samples"], st["closest_rays"], st["shadow_rays"]
-    shaded = C                       # one shade item per closest-hit ray
     if info.flat_prims:
-        ex_c = st["exact_tests"] * C / max(1, C + SH)       # the exact-test counter is not split by kernel class
-        ex_s = st["exact_tests"] - ex_c
-        scene_c = st["closest_prims"] * 64 / 64.0 + ex_c * rec
-        scene_s = st["shadow_prims"] * 64 / 64.0 + ex_s * rec
+        dem_c = dem_s = 0.0                                 # the flat table arrives through scalar loads, once per wave
     else:
-        scene_c = st["closest_nodes"] * node + st["closest_prims"] * rec
-        scene_s = st["shadow_nodes"] * node + st["shadow_prims"] * rec
+        dem_c = st["closest_nodes"] * node + st["closest_prims"] * rec
+        dem_s = st["shadow_nodes"] * node + st["shadow_prims"] * rec
+    cont = C - S                                            # entries written into the next queue over all bounces
     b = [0.0] * 5
-    b[0] = S * (7 * 16 + 8)                                          # ray_o ray_d beta L lambda pdf rng + misc
-    b[1] = C * (4 + 8 + 32 + 16) + scene_c
-    b[2] = shaded * (4 + 8 + 16 + 16 + 16 + 16 + 16 + 8)             # queue misc hit beta lambda ray_d rng(16 r + 8 w)
-    b[2] += (C - S) * (32 + 16 + 8 + 4) + SH * (48 + 4) + shaded * 72   # continuation + shadow-ray writes + shading record
-    b[3] = SH * (4 + 32) + scene_s + SH * 48
-    b[4] = S * (48 + 8) + (S / max(1, st["spp_rendered"])) * 64
-    return b
+    b[0] = S * (16 + 16 + 16 + 16 + 8 + 16 + 16 + 16 + 4)                # ro rd beta lambda rng | L lambda_s pdf fw
+    b[1] = C * (32 + 16)                                                 # ro rd in, hit out
+    b[2] = C * (16 + 16 + 16 + 16 + 8 + 16) + cont * (16 + 16 + 16 + 16 + 8) + SH * 48   # state + hit in; survivors + shadow entries out
+    b[3] = SH * (48 + 32)                                                # shadow entry in; L read-modify-write (unoccluded: upper bound)
+    b[4] = S * (16 + 16 + 16 + 4) + (S / max(1, spp_rendered)) * 64      # L lambda pdf fw in, film pixel RMW
+    demand = list(b)
+    demand[1] += dem_c
+    demand[3] += dem_s
+    if not resident:
+        b[1] += dem_c
+        b[3] += dem_s
+    return b, demand, resident
 
 
-def note(msg):
-    """progress on stderr (stdout carries only the JSON line)"""
-    print(f"[bench] {msg}", file=sys.stderr, flush=True)
-
-
-def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup):
-    note("building scene")
-    if args.workload == "c4":      # BASELINE.json configs[3]: 20,971,520 triangles, 3840x2160 @ 256 spp, uniform sky
-        rw, rh = (args.res or 3840), ((args.res or 3840) * 9) // 16
-        n_blobs = args.blobs if args.blobs != 1024 else 20480
+def make_scene(args, pm, workload):
+    """(scene description, name, resolution, spp per unit of work, max_depth, integrator, split) of a path-tracing leg"""
+    C = pm._capi
+    if workload == "c4":      # BASELINE.json configs[3]: 20,971,520 triangles, 3840x2160 @ 256 spp, uniform sky
+        rw = args.res or 3840
+        rh = rw * 9 // 16
+        n_blobs = args.blobs or 20480
         sd = pm.scenes.blob_sky_scene(n_blobs, (rw, rh))
-        spp = args.spp if args.spp != 64 else 256
-        name = f"C4 {n_blobs * 1024} diffuse triangles under a uniform sky: {rw}x{rh} @ {spp} spp per GPU"
-    else:
+        spp = args.spp or 256
+        name = f"C4 {n_blobs * 1024} diffuse triangles under a uniform sky: {rw}x{rh}"
+        return sd, name, (rw, rh), spp, args.max_depth or 5, C.PM_INTEGRATOR_SIMPLE_PATH, args.split or "hlbvh"
+    if workload == "c5":      # BASELINE.json configs[4]
         rw = rh = args.res or 1024
-        sd = pm.scenes.cornell_scene((rw, rh))
-        spp = args.spp
-        name = f"C2 Cornell box path tracing: {rw}x{rh} @ {spp} spp per GPU"
-    spp_total = spp * world
-    integ = pm.WavefrontIntegrator(args.max_depth, True, True, sd, spp_total, seed=0, device_id=local_rank,
-                                   split_method=pm._capi.PM_SPLIT_HLBVH if args.split == "hlbvh" else pm._capi.PM_SPLIT_SAH,
+        sd = pm.scenes.c5_scene((rw, rh))
+        name = (f"C5 Cornell box + 0.5x0.5 quad area light + homogeneous medium in the box (sigma_s 1.0, sigma_a 0.05, g 0.6), "
+                f"VolPath: {rw}x{rh}")
+        return sd, name, (rw, rh), args.spp or 64, args.max_depth or 16, C.PM_INTEGRATOR_VOL_PATH, args.split or "sah"
+    rw = rh = args.res or 1024
+    sd = pm.scenes.cornell_scene((rw, rh))
+    name = f"C2 Cornell box (34 triangles + 1 glass sphere, PointLight: the reference has no area light): {rw}x{rh}"
+    return sd, name, (rw, rh), args.spp or 64, args.max_depth or 5, C.PM_INTEGRATOR_SIMPLE_PATH, args.split or "sah"
+
+
+def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup, workload, spp_override=None):
+    note(f"building scene ({workload})")
+    sd, name, (rw, rh), spp, max_depth, integrator, split = make_scene(args, pm, workload)
+    if spp_override:
+        spp = spp_override
+    strong = args.scaling == "strong" and world > 1
+    spp_total = spp if strong else spp * world
+    integ = pm.WavefrontIntegrator(max_depth, True, True, sd, spp_total, seed=0, device_id=local_rank, integrator=integrator,
+                                   split_method=pm._capi.PM_SPLIT_HLBVH if split == "hlbvh" else pm._capi.PM_SPLIT_SAH,
                                    max_prims_in_node=args.max_leaf)
-    s0, s1 = pm.distributed.shard_samples(spp_total, rank, world)
+    rows = args.merge == "rows" and world > 1
+    if rows:
+        window = pm.distributed.shard_rows(sd.film["pixel_bounds"], rank, world)
+        s0, s1 = 0, spp_total
+    else:
+        window = None
+        s0, s1 = pm.distributed.shard_samples(spp_total, rank, world)
     film = torch.empty((rh, rw, 4), dtype=torch.float64, device="cuda")
+    merged = {}
 
     def step():
         integ.clear()
-        st = integ.render(samples=(s0, s1))
+        st = integ.render(window=window, samples=(s0, s1))
         if world > 1:
             integ.film(out=film)
-            pm.distributed.allreduce_film(film)
+            if rows:
+                merged["film"] = pm.distributed.allgather_rows(film, sd.film["pixel_bounds"])
+            else:
+                pm.distributed.allreduce_film(film)
         return st
 
     def barrier():
@@ -297,12 +371,14 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup):
         torch.cuda.synchronize()
 
     # untimed counting pass -> algorithmic bytes per kernel class
-    note(f"scene ready ({integ.aggregate.info.n_prims} primitives, {integ.aggregate.info.n_nodes} nodes); counting pass")
+    info = integ.aggregate.info
+    note(f"scene ready ({info.n_prims} primitives, {info.n_nodes} nodes, built in {info.build_seconds:.2f} s); counting pass")
     integ.aggregate.set_counting(True)
     st_c = step()
     integ.aggregate.set_counting(False)
-    st_c["spp_rendered"] = s1 - s0
-    bytes_k = kernel_bytes(st_c, integ.aggregate.info, sd)
+    ext = integrator == pm._capi.PM_INTEGRATOR_VOL_PATH
+    bytes_k, demand_k, resident = kernel_bytes(st_c, info, s1 - s0, ext)
+    q_closest, q_shadow = integ.queue_counts()
     note("timed steps")
     for _ in range(warmup):
         step()
@@ -323,21 +399,46 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup):
     ms_k /= steps
     launches /= steps
     samples = st["samples"]
+    total_samples = samples * world if not rows else rw * rh * spp_total
+    if world > 1 and not rows:
+        total_samples = rw * rh * spp_total
     dom = int(np.argmax(ms_k))
     achieved = bytes_k[dom] / (ms_k[dom] * 1e-3) / 1e9
     total_bytes = float(sum(bytes_k))
+    tag = {"path": "path", "c4": "c4", "c5": "c5"}[workload]
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "kernel": KERNEL_NAMES[dom], "kernel_ms": float(ms_k[dom] / max(1.0, launches[dom])),
+            "launches_per_step": float(launches[dom]), "bytes_per_launch": bytes_k[dom] / max(1.0, launches[dom]),
+            "demand_GBps": demand_k[dom] / (ms_k[dom] * 1e-3) / 1e9,
+            "scene_resident_in_infinity_cache": bool(resident),
+            "whole_render": {"achieved": total_bytes / (float(ms_k.sum()) * 1e-3) / 1e9,
+                             "frac": total_bytes / (float(ms_k.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "per_kernel": {k: {"ms": float(m), "GBps": float(b / (m * 1e-3) / 1e9) if m > 0 else 0.0,
+                               "frac": float(b / (m * 1e-3) / 1e9 / HBM_PEAK_GBS) if m > 0 else 0.0,
+                               **{kk: vv for kk, vv in pmc_fields(PMC_NAME[k], tag).items() if kk in ("traffic", "issue")}}
+                           for k, b, m in zip(KERNEL_NAMES, bytes_k, ms_k)}}
+    roof.update(pmc_fields(PMC_NAME[KERNEL_NAMES[dom]], tag))
+    if KERNEL_NAMES[dom] in ("closest_kernel", "shadow_kernel"):
+        roof["note"] = ("the dominant kernel is a traversal kernel: bound by VALU issue (`issue`), its algorithmic HBM bytes are "
+                        + ("the rays and hits alone (the scene is cache-resident%s)" % (": a lock-step flat sweep of %d primitives from scalar-loaded "
+                                                                                      "records" % info.flat_prims if info.flat_prims else "")
+                           if resident else "rays, hits and the node / record fetches of a scene larger than the Infinity Cache"))
     out = {
-        "metric": "path samples/s", "value": samples * world * steps / dt, "unit": "samples/s", "n_gpus": world,
-        "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "metric": "path samples/s", "value": total_samples * steps / dt, "unit": "samples/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{name}, SimplePathIntegrator max_depth {args.max_depth}, light + BSDF sampling, "
+        "config": {"workload": f"{name} @ {spp_total} spp in total ({s1 - s0} sample indices"
+                               f"{' x a row band' if rows else ''} per GPU), max_depth {max_depth}, light + BSDF sampling, "
                                f"Gaussian filter, 4 wavelengths/sample",
-                   "bvh_nodes": int(integ.aggregate.info.n_nodes), "bvh_build": args.split,
-                   "traversal": ("flat sweep of %d primitives (no tree walk)" % integ.aggregate.info.flat_prims
-                                 if integ.aggregate.info.flat_prims else "wide-BVH walk"),
-                   "bvh_build_seconds": float(integ.aggregate.info.build_seconds),
+                   "integrator": {0: "SimplePath", 1: "RandomWalk", 2: "VolPath (SimplePath + homogeneous medium, extension)"}[integrator],
+                   "bvh_nodes": int(info.n_nodes), "bvh_build": split,
+                   "traversal": ("flat sweep of %d primitives (no tree walk)" % info.flat_prims if info.flat_prims else "wide-BVH walk"),
+                   "bvh_build_seconds": float(info.build_seconds),
                    "samples_per_gpu": samples, "closest_rays": st["closest_rays"], "shadow_rays": st["shadow_rays"],
-                   "passes": st["passes"], "merge": "none" if world == 1 else ("RCCL" if args.backend == "nccl" else args.backend) + " all-reduce of the f64 film per step",
+                   "passes": st["passes"],
+                   "merge": "none" if world == 1 else ("RCCL" if args.backend == "nccl" else args.backend) +
+                            (" all-gather of row bands" if rows else " all-reduce of the f64 film") + " per step",
                    "bytes_per_sample": total_bytes / samples,
                    "closest_nodes_per_ray": st_c["closest_nodes"] / max(1, st_c["closest_rays"]),
                    "closest_prims_per_ray": st_c["closest_prims"] / max(1, st_c["closest_rays"]),
@@ -345,27 +446,19 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup):
                    "shadow_prims_per_ray": st_c["shadow_prims"] / max(1, st_c["shadow_rays"]),
                    "exact_tests_per_ray": st_c["exact_tests"] / max(1, st_c["closest_rays"] + st_c["shadow_rays"]),
                    "fallback_walks": st_c["fallback_walks"],
-                   "kernel_ms": dict(zip(KERNEL_NAMES, [float(x) for x in ms_k])),
-                   "kernel_GBps": dict(zip(KERNEL_NAMES, [float(b / (m * 1e-3) / 1e9) if m > 0 else 0.0
-                                                          for b, m in zip(bytes_k, ms_k)]))},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(PMC_NAME[KERNEL_NAMES[dom]], "path")[0] if args.workload == "path" else None,
-                     "traffic_source": pmc_traffic(PMC_NAME[KERNEL_NAMES[dom]], "path")[1] if args.workload == "path" else None,
-                     "kernel": KERNEL_NAMES[dom],
-                     "kernel_ms": float(ms_k[dom] / max(1.0, launches[dom])), "launches_per_step": float(launches[dom]),
-                     "bytes_per_launch": bytes_k[dom] / max(1.0, launches[dom]),
-                     "whole_render": {"achieved": total_bytes / (float(ms_k.sum()) * 1e-3) / 1e9,
-                                      "frac": total_bytes / (float(ms_k.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                     "per_kernel_frac": {k: float(b / (m * 1e-3) / 1e9 / HBM_PEAK_GBS) if m > 0 else 0.0
-                                         for k, b, m in zip(KERNEL_NAMES, bytes_k, ms_k)}},
+                   "queue_entries_per_bounce": {"closest": [int(x) for x in q_closest], "shadow": [int(x) for x in q_shadow],
+                                                "occupancy": [float(x) / max(1.0, float(q_closest[0])) for x in q_closest]},
+                   "generator": "numpy PCG64 (default_rng); see scenes.py"},
+        "roofline": roof,
     }
-    if integ.aggregate.info.flat_prims and KERNEL_NAMES[dom] in ("closest_kernel", "shadow_kernel"):
-        out["roofline"]["note"] = ("the traversal kernels of this %d-primitive scene are instruction-bound by design: every wave "
-                                   "sweeps all primitives from wave-uniform (scalar-loaded) records, so their algorithmic HBM "
-                                   "bytes are a few tens of bytes per ray; the HBM-bound kernel of the frame is shade_kernel "
-                                   "(per_kernel_frac)" % integ.aggregate.info.flat_prims)
-    return out, sd, integ
+    return out, sd, integ, (spp, max_depth, integrator)
+
+
+def sub(out, keys=("value", "unit", "ms_per_step", "roofline", "cpu_baseline")):
+    d = {k: out[k] for k in keys if k in out}
+    d["workload"] = out["config"]["workload"]
+    d["config"] = {k: v for k, v in out["config"].items() if k != "workload"}
+    return d
 
 
 def main():
@@ -386,22 +479,41 @@ def main():
             dist.init_process_group(args.backend)
     pm = importlib.import_module("pbrt-rs_amd")
     want_cpu = world == 1 and not args.no_cpu_baseline
+    ctx = (args, pm, torch, dist, rank, local_rank, world)
 
     if args.workload == "trace":
-        out = run_trace(args, pm, torch, dist, rank, local_rank, world, args.steps, args.warmup, want_cpu)
+        out = run_trace(*ctx, args.steps, args.warmup, want_cpu)
     else:
-        out, sd, integ = run_path(args, pm, torch, dist, rank, local_rank, world, args.steps, args.warmup)
-        if want_cpu and rank == 0 and args.workload == "path":
-            threads = min(16, len(os.sched_getaffinity(0)))
-            out["cpu_baseline"] = cpu_baseline_path(pm, sd, args.spp, args.max_depth, threads, args.cpu_seconds)
-        del integ
-        if not args.no_secondary and args.workload == "path":
-            tr = run_trace(args, pm, torch, dist, rank, local_rank, world, max(3, args.steps), 1, False)
-            out["closest_hit"] = {"value": tr["value"], "unit": tr["unit"], "workload": tr["config"]["workload"],
-                                  "ms_per_step": tr["ms_per_step"], "roofline": tr["roofline"]}
+        out, sd, integ, (spp, max_depth, integrator) = run_path(*ctx, args.steps, args.warmup, args.workload)
+        if want_cpu and rank == 0:
+            note("cpu baseline")
+            rows = (0, 64) if args.workload == "c4" else None
+            out["cpu_baseline"] = cpu_baseline_path(pm, sd, spp, max_depth, cpu_threads(), args.cpu_seconds, integrator, rows)
+        integ.aggregate.close()
+        del integ, sd
+        if args.workload == "path" and not args.no_secondary:
+            k = max(3, min(args.steps, 5))
+            tr = run_trace(*ctx, k, 1, want_cpu)
+            out["closest_hit"] = sub(tr)
             for key in ("shadow_any_hit", "incoherent_closest_hit"):
                 if key in tr:
                     out["closest_hit"][key] = tr[key]
+            if world == 1:
+                # the wide-BVH path tracer at C4 scale, one pass of 2^26 paths; and C5 (area light + medium, depth 16)
+                c4, sd4, integ4, (spp4, d4, i4) = run_path(*ctx, 3, 1, "c4", spp_override=8)
+                if want_cpu:
+                    note("C4 cpu baseline (64-row band; builds the reference-layout BVH of 21 M triangles first)")
+                    c4["cpu_baseline"] = cpu_baseline_path(pm, sd4, spp4, d4, cpu_threads(), args.cpu_seconds, i4, rows=(1048, 1112))
+                integ4.aggregate.close()
+                del integ4, sd4
+                out["c4_path"] = sub(c4)
+                c5, sd5, integ5, (spp5, d5, i5) = run_path(*ctx, 3, 1, "c5", spp_override=8)
+                if want_cpu:
+                    note("C5 cpu baseline")
+                    c5["cpu_baseline"] = cpu_baseline_path(pm, sd5, spp5, d5, cpu_threads(), min(args.cpu_seconds, 8.0), i5)
+                integ5.aggregate.close()
+                del integ5, sd5
+                out["c5_path"] = sub(c5)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

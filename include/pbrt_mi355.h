@@ -249,6 +249,9 @@ int pm_film_add(pm_ctx* ctx, const double* rgbw);
 /* RGBFilm::get_pixel_rgb for every pixel (camera/film.rs:261-279): 3 floats per pixel */
 int pm_film_image(pm_ctx* ctx, float* rgb);
 int pm_get_render_stats(pm_ctx* ctx, PmRenderStats* out);
+/* queue occupancy of the last pm_render: entries of the closest-hit queue and of the shadow queue at bounce 0 .. max_depth
+ * (summed over passes); *n_bounces receives max_depth + 1, at most cap entries are written to each array (either may be NULL) */
+int pm_get_queue_counts(pm_ctx* ctx, uint64_t* closest, uint64_t* shadow, uint32_t cap, uint32_t* n_bounces);
 /* test hook: unweighted radiance L[4] + lambda[4] + pdf[4] + filter weight of ONE (pixel, sample), recomputed
  * on the device with the same kernels (13 floats) */
 int pm_debug_sample(pm_ctx* ctx, const PmRenderParams* params, int32_t px, int32_t py, int32_t sample_index, float* out13);

@@ -126,6 +126,7 @@ SYMBOLS = {
     "pm_film_add": (C.c_int, [_P, _P]),
     "pm_film_image": (C.c_int, [_P, _P]),
     "pm_get_render_stats": (C.c_int, [_P, C.POINTER(PmRenderStats)]),
+    "pm_get_queue_counts": (C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     "pm_debug_sample": (C.c_int, [_P, C.POINTER(PmRenderParams), C.c_int32, C.c_int32, C.c_int32, _P]),
     "pm_debug_uniforms": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32, _P]),
     # include/pbrt_mi355_host.h

@@ -787,6 +787,7 @@ struct RenderState {
     PathArrays pa{}; size_t pa_cap = 0; int pa_depth = 0;
     std::vector<void*> pa_allocs;
     PmRenderStats stats{};
+    std::vector<uint64_t> q_closest, q_shadow;      // queue entries per bounce of the last render (all passes)
     std::vector<hipEvent_t> ev_pool;      // per-launch timing: one event before every kernel of a pass + one after
 };
 
@@ -1082,6 +1083,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     int rcode;
     if (r->scene_dirty || r->geom_gen != c->geom_gen) if ((rcode = upload_scene(c, r))) return rcode;
     r->stats = PmRenderStats{};
+    r->q_closest.assign((size_t)p->max_depth + 1, 0); r->q_shadow.assign((size_t)p->max_depth + 1, 0);
     r->stats.state_bytes_per_path = PM_PATH_BYTES;
     const int W = x1 - x0, H = y1 - y0;
     if (W == 0 || H == 0 || s0 == s1) return PM_OK;
@@ -1220,6 +1222,10 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
         r->stats.samples += (uint64_t)W * H * rc.s_count;
         // closest rays: every live path in the queue of bounce b (padded slots are not live)
         const uint64_t pad = (uint64_t)(npix_pad - (size_t)W * H) * rc.s_count;
+        for (int b = 0; b <= p->max_depth; ++b) {
+            r->q_closest[b] += hcounts[(size_t)b * PM_CNT_STRIDE] - (b == 0 ? pad : 0);
+            r->q_shadow[b] += hcounts[(size_t)(nb + b) * PM_CNT_STRIDE];
+        }
         for (int b = 0; b <= p->max_depth; ++b) r->stats.closest_rays += hcounts[(size_t)b * PM_CNT_STRIDE] - (b == 0 ? pad : 0);
         for (int b = 0; b < nb; ++b) r->stats.shadow_rays += hcounts[(size_t)(nb + b) * PM_CNT_STRIDE];
     }
@@ -1274,6 +1280,16 @@ extern "C" int pm_debug_uniforms(pm_ctx* c, int32_t px, int32_t py, uint32_t see
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(c, PM_ERR_HIP, std::string("pm_debug_uniforms: ") + hipGetErrorString(e));
+    return PM_OK;
+}
+extern "C" int pm_get_queue_counts(pm_ctx* c, uint64_t* closest, uint64_t* shadow, uint32_t cap, uint32_t* n_bounces) {
+    if (!c || !c->render) return fail(c, PM_ERR_INVALID, "pm_get_queue_counts: nothing rendered");
+    const RenderState* r = c->render;
+    if (n_bounces) *n_bounces = (uint32_t)r->q_closest.size();
+    for (uint32_t b = 0; b < cap && b < r->q_closest.size(); ++b) {
+        if (closest) closest[b] = r->q_closest[b];
+        if (shadow) shadow[b] = r->q_shadow[b];
+    }
     return PM_OK;
 }
 extern "C" int pm_get_render_stats(pm_ctx* c, PmRenderStats* out) {

@@ -96,6 +96,14 @@ class WavefrontIntegrator:
             out[k] = list(v) if hasattr(v, "__len__") else v
         return out
 
+    def queue_counts(self):
+        """(closest-hit queue entries, shadow queue entries) per bounce of the last render()"""
+        n = C.c_uint32()
+        self.aggregate._check(self._lib.pm_get_queue_counts(self._h, None, None, 0, C.byref(n)))
+        a, b = np.zeros(n.value, np.uint64), np.zeros(n.value, np.uint64)
+        self.aggregate._check(self._lib.pm_get_queue_counts(self._h, a.ctypes.data, b.ctypes.data, n.value, None))
+        return a, b
+
     def debug_sample(self, px, py, sample_index):
         """(L[4], lambda[4], pdf[4], filter_weight) of one (pixel, sample) — test hook."""
         out = np.zeros(13, np.float32)
