@@ -6,7 +6,7 @@
 //   1. morton_kernel     63-bit Morton code of every primitive centroid (util/routines.rs:34-50 encode_morton_3 widened)
 //   2. hipcub radix sort of (code, primitive index)          - HBM-bound: 2 x 12 B per primitive per pass
 //   3. radix_tree_kernel binary radix tree over the sorted codes (Karras 2012), one thread per internal node
-//   4. refit_kernel      bottom-up boxes, one thread per leaf, second arrival at a node continues
+//   4. leafbox / rmq_level / node_box kernels   boxes of the internal nodes as range queries over the sorted leaf boxes
 //   5. collapse_kernel   level by level: one thread per wide node opens up to 8 binary descendants (largest area first),
 //                        assigns them to octant slots, quantises the child boxes exactly like the host builder
 //                        (pm_build.cpp) and gathers the leaf records
@@ -105,25 +105,41 @@ __device__ __forceinline__ GBox box_of(uint32_t ref, const GBox* ibox, const pm:
     return ibox[ref];
 }
 
-__global__ void refit_kernel(const pm::HostTri* __restrict__ tris, const uint32_t* __restrict__ sorted, int n,
-                             const uint2* __restrict__ children, const uint32_t* __restrict__ parent_of_internal,
-                             const uint32_t* __restrict__ parent_of_leaf, GBox* ibox, uint32_t* flags) {
+// ---- boxes of the internal nodes WITHOUT a bottom-up walk.  Internal node i of the radix tree covers the contiguous run
+// [first, last] of the sorted leaves, so its box is a range-min/max query over the leaf boxes: a sparse table
+//   T[0][j] = box of sorted leaf j,   T[k][j] = T[k-1][j] U T[k-1][min(j + 2^(k-1), n-1)]
+// (log2(n) streaming passes), then one thread per internal node takes the union of two overlapping power-of-two windows.
+// min / max are exact and associative, so the boxes are bit-identical to a bottom-up refit.  Round 1's refit (one thread per
+// leaf climbing the tree, an atomic and two agent-scope fences per level) took 134 ms of the 256 ms build of the 21 M-triangle
+// scene; this takes a few ms and K * n * 24 bytes of scratch (12.6 GB for that scene: the device has 288 GB).
+__global__ void leafbox_kernel(const pm::HostTri* __restrict__ tris, const uint32_t* __restrict__ sorted, int n, GBox* __restrict__ out) {
     const int i = blockIdx.x * GB_BLOCK + threadIdx.x;
     if (i >= n) return;
-    uint32_t node = parent_of_leaf[i];
-    while (node != 0xFFFFFFFFu) {
-        // the first thread to arrive leaves; the second finds both children complete
-        if (atomicAdd(&flags[node], 1u) == 0u) return;
-        __threadfence();
-        const uint2 ch = children[node];
-        const GBox a = box_of(ch.x, ibox, tris, sorted), b = box_of(ch.y, ibox, tris, sorted);
-        GBox r;
-        for (int k = 0; k < 3; ++k) { r.lo[k] = fminf(a.lo[k], b.lo[k]); r.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
-        // volatile-style publication: plain stores followed by a fence before the parent's counter is touched
-        ibox[node] = r;
-        __threadfence();
-        node = parent_of_internal[node];
-    }
+    const pm::Box& b = tris[sorted[i]].bounds;
+    GBox r;
+    for (int k = 0; k < 3; ++k) { r.lo[k] = b.lo[k]; r.hi[k] = b.hi[k]; }
+    out[i] = r;
+}
+__device__ __forceinline__ GBox box_union(const GBox& a, const GBox& b) {
+    GBox r;
+    for (int k = 0; k < 3; ++k) { r.lo[k] = fminf(a.lo[k], b.lo[k]); r.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
+    return r;
+}
+__global__ void rmq_level_kernel(const GBox* __restrict__ prev, GBox* __restrict__ cur, int n, int half) {
+    const int i = blockIdx.x * GB_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int j = i + half < n ? i + half : n - 1;
+    cur[i] = box_union(prev[i], prev[j]);
+}
+__global__ void node_box_kernel(const uint2* __restrict__ range, int n_internal, const GBox* __restrict__ table, size_t n,
+                                GBox* __restrict__ ibox) {
+    const int i = blockIdx.x * GB_BLOCK + threadIdx.x;
+    if (i >= n_internal) return;
+    const uint2 r = range[i];
+    const uint32_t len = r.y - r.x + 1u;
+    const int k = 31 - __clz(len);
+    const GBox* lvl = table + (size_t)k * n;
+    ibox[i] = box_union(lvl[r.x], lvl[r.y + 1u - (1u << k)]);
 }
 
 __device__ __forceinline__ float area_of(const GBox& b) {
@@ -297,7 +313,7 @@ int pm_gpu_build_tris(pm_ctx* c, int max_leaf, std::string& err) {
         for (int k = 0; k < 3; ++k) { scene.lo[k] = std::fmin(scene.lo[k], t.bounds.lo[k]); scene.hi[k] = std::fmax(scene.hi[k], t.bounds.hi[k]); }
 
     hipStream_t st = c->stream;
-    DevBuf tris, keys, keys2, vals, vals2, temp, children, range, par_i, par_l, ibox, flags, q0, q1, counters, big_nodes;
+    DevBuf tris, keys, keys2, vals, vals2, temp, children, range, par_i, par_l, ibox, q0, q1, counters, big_nodes;
     GBCHK(tris.alloc(n * sizeof(pm::HostTri)));
     GBCHK(hipMemcpyAsync(tris.p, sc.tris.data(), n * sizeof(pm::HostTri), hipMemcpyHostToDevice, st));
     GBCHK(keys.alloc(n * 8)); GBCHK(keys2.alloc(n * 8)); GBCHK(vals.alloc(n * 4)); GBCHK(vals2.alloc(n * 4));
@@ -311,12 +327,22 @@ int pm_gpu_build_tris(pm_ctx* c, int max_leaf, std::string& err) {
     GBCHK(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, keys.as<unsigned long long>(), keys2.as<unsigned long long>(),
                                              vals.as<uint32_t>(), vals2.as<uint32_t>(), (int)n, 0, 63, st));
     GBCHK(children.alloc((n - 1) * 8)); GBCHK(range.alloc((n - 1) * 8)); GBCHK(par_i.alloc((n - 1) * 4)); GBCHK(par_l.alloc(n * 4));
-    GBCHK(ibox.alloc((n - 1) * sizeof(GBox))); GBCHK(flags.alloc((n - 1) * 4));
-    GBCHK(hipMemsetAsync(flags.p, 0, (n - 1) * 4, st));
+    GBCHK(ibox.alloc((n - 1) * sizeof(GBox)));
     hipLaunchKernelGGL(radix_tree_kernel, dim3(grid_n), dim3(GB_BLOCK), 0, st, keys2.as<unsigned long long>(), (int)n,
                        children.as<uint2>(), range.as<uint2>(), par_i.as<uint32_t>(), par_l.as<uint32_t>());
-    hipLaunchKernelGGL(refit_kernel, dim3(grid_n), dim3(GB_BLOCK), 0, st, tris.as<pm::HostTri>(), vals2.as<uint32_t>(), (int)n,
-                       children.as<uint2>(), par_i.as<uint32_t>(), par_l.as<uint32_t>(), ibox.as<GBox>(), flags.as<uint32_t>());
+    {   // internal-node boxes by range queries over the sorted leaf boxes (see leafbox_kernel)
+        int levels = 1;
+        while ((1ull << levels) <= n) ++levels;                 // levels 0 .. floor(log2(n))
+        DevBuf table;
+        GBCHK(table.alloc((size_t)levels * n * sizeof(GBox)));
+        GBox* T = table.as<GBox>();
+        hipLaunchKernelGGL(leafbox_kernel, dim3(grid_n), dim3(GB_BLOCK), 0, st, tris.as<pm::HostTri>(), vals2.as<uint32_t>(), (int)n, T);
+        for (int k = 1; k < levels; ++k)
+            hipLaunchKernelGGL(rmq_level_kernel, dim3(grid_n), dim3(GB_BLOCK), 0, st, T + (size_t)(k - 1) * n, T + (size_t)k * n, (int)n,
+                               1 << (k - 1));
+        hipLaunchKernelGGL(node_box_kernel, dim3(grid_n), dim3(GB_BLOCK), 0, st, range.as<uint2>(), (int)(n - 1), T, n, ibox.as<GBox>());
+        GBCHK(hipStreamSynchronize(st));                        // the table is freed when this scope ends
+    }
     GBCHK(hipGetLastError());
 
     // collapse, level by level.  A wide node always roots at a binary node with more than max_leaf primitives, so there

@@ -28,11 +28,13 @@ enum { PM_PRIM_SPHERE = 0, PM_PRIM_PATCH = 1, PM_PRIM_TRI = 2 };
 // record sizes in 16-byte units
 #define PM_UNITS_SPHERE 5
 #define PM_UNITS_PATCH 4
+#ifndef PM_UNITS_TRI
 #define PM_UNITS_TRI 3
+#endif
 
 struct alignas(16) PmTriRecord {      // 48 B: degenerate patch p00=v0 p10=v1 p01=v2 p11=v2
     float v0[3]; float v1[3]; float v2[3];
-    uint32_t prim_id; uint32_t pad[2];
+    uint32_t prim_id; uint32_t pad[2 + 4 * (PM_UNITS_TRI - 3)];
 };
 struct alignas(16) PmPatchRecord {    // 64 B
     float p00[3]; float p10[3]; float p01[3]; float p11[3];
@@ -45,7 +47,7 @@ struct alignas(16) PmSphereRecord {   // 80 B; object_from_render rows 0..2 (aff
     float m_norm;     // max over rows of |m_r0| + |m_r1| + |m_r2|   } error scales of the float pre-filter
     float t_norm;     // max over rows of |m_r3|                     } (pm_device.hpp sphere_prefilter)
 };
-static_assert(sizeof(PmTriRecord) == 48 && sizeof(PmPatchRecord) == 64 && sizeof(PmSphereRecord) == 80, "record sizes");
+static_assert(sizeof(PmTriRecord) == 16 * PM_UNITS_TRI && sizeof(PmPatchRecord) == 64 && sizeof(PmSphereRecord) == 80, "record sizes");
 
 // Scenes of at most PM_FLAT_MAX_PRIMS primitives are not walked at all: every wave sweeps ALL primitives in lock step
 // (wave-uniform records, no divergence, no node steps), which beats any tree of that size on 64-lane SIMT hardware.

@@ -1,0 +1,19 @@
+#!/bin/bash
+# GPU box: tree-walk workloads (C3 ray sets + C4-shaped path tracing, device-built tree) with several builds of the library
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+OUT=gpurun_out/ab_trav.log
+: > $OUT
+for lib in "" "$@"; do
+  echo "== lib=${lib:-current}" >> $OUT
+  PBRT_MI355_LIB=${lib:+$R/$lib} timeout -k 10 200 python -u bench.py --workload trace --steps 5 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('C3 primary %.0f shadow %.0f incoherent %.0f Mrays/s' % (d['value'], d['shadow_any_hit']['value'], d['incoherent_closest_hit']['value']))" >> $OUT 2>&1 || exit 1
+  PBRT_MI355_LIB=${lib:+$R/$lib} timeout -k 10 300 python -u bench.py --workload c4 --blobs 4096 --res 1920 --spp 16 --steps 2 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('C4-small %.1f Msamples/s  kernel_ms %s' % (d['value']/1e6, {k: round(v['ms'],1) for k,v in d['roofline']['per_kernel'].items()}))" >> $OUT 2>&1 || exit 1
+done
+cat $OUT
