@@ -264,4 +264,25 @@ int pm_debug_uniforms(pm_ctx* ctx, int32_t px, int32_t py, uint32_t seed, uint64
 #ifdef __cplusplus
 }
 #endif
+
+/* Layout contract of the structs above (LP64): bindings in other languages (rust/pbrt-mi355-sys, pbrt-rs_amd/_capi.py) are
+ * checked against these sizes by tests/test_rust_bindings.py. */
+#ifdef __cplusplus
+#define PM_STATIC_ASSERT(c, m) static_assert(c, m)
+#else
+#define PM_STATIC_ASSERT(c, m) _Static_assert(c, m)
+#endif
+PM_STATIC_ASSERT(sizeof(PmRay) == 32, "PmRay");
+PM_STATIC_ASSERT(sizeof(PmHit) == 16, "PmHit");
+PM_STATIC_ASSERT(sizeof(PmSphere) == 152, "PmSphere");
+PM_STATIC_ASSERT(sizeof(PmAccelInfo) == 80, "PmAccelInfo");
+PM_STATIC_ASSERT(sizeof(PmCounters) == 48, "PmCounters");
+PM_STATIC_ASSERT(sizeof(PmSpectrum) == 32, "PmSpectrum");
+PM_STATIC_ASSERT(sizeof(PmMaterial) == 56, "PmMaterial");
+PM_STATIC_ASSERT(sizeof(PmLight) == 88, "PmLight");
+PM_STATIC_ASSERT(sizeof(PmMedium) == 48, "PmMedium");
+PM_STATIC_ASSERT(sizeof(PmCamera) == 136, "PmCamera");
+PM_STATIC_ASSERT(sizeof(PmFilm) == 112, "PmFilm");
+PM_STATIC_ASSERT(sizeof(PmRenderParams) == 48, "PmRenderParams");
+PM_STATIC_ASSERT(sizeof(PmRenderStats) == 184, "PmRenderStats");
 #endif
