@@ -96,6 +96,13 @@ int pm_add_spheres(pm_ctx* ctx, const PmSphere* spheres, uint32_t n, uint32_t* f
 int pm_add_patch_mesh(pm_ctx* ctx, const float* pos_xyz, uint32_t n_vert, const uint32_t* idx4, uint32_t n_patch,
                       const float* normals_or_null, int reverse_orientation, int transform_swaps_handedness,
                       uint32_t* first_prim_id);
+/* ... with per-vertex texture coordinates (BilinearPatchMesh.uv, shapes/bilinear_patch.rs:621-622; n_vert x 2 floats, may be
+ * NULL).  The reference stores them but never uses them ("TODO: Skipping this part for now", bilinear_patch.rs:103-112); here
+ * a textured material is looked up at st = lerp(lerp(uv00, uv01, v), lerp(uv10, uv11, v), u) (pbrt-v4's formula); without
+ * them st = the patch's own (u, v). */
+int pm_add_patch_mesh_uv(pm_ctx* ctx, const float* pos_xyz, uint32_t n_vert, const uint32_t* idx4, uint32_t n_patch,
+                         const float* normals_or_null, const float* uv_or_null, int reverse_orientation,
+                         int transform_swaps_handedness, uint32_t* first_prim_id);
 /* No triangle shape exists in the reference (shapes/base.rs:8-13). A triangle (v0,v1,v2) is intersected
  * exactly as the reference intersects the degenerate patch p00=v0,p10=v1,p01=v2,p11=v2
  * (shapes/bilinear_patch.rs:506-612). */
@@ -153,13 +160,20 @@ enum { PM_SPEC_CONSTANT = 0,        /* a = c                                   (
        PM_SPEC_BLACKBODY = 5 };     /* a = T [K], b = normalisation factor     (:376-437) */
 typedef struct PmSpectrum { int32_t kind; float a, b, c, d; const float* table; } PmSpectrum;
 
-/* materials/material.rs:111-201 (constant textures only, as in the reference) */
+/* materials/material.rs:111-201.  The reference has constant textures only (materials/textures.rs:63-90).  EXTENSION for
+ * scenes/test.pbrt: texture == PM_TEX_CHECKERBOARD makes a DIFFUSE material's reflectance a 2-D checkerboard of `spectrum`
+ * (tex1) and `spectrum2` (tex2) over st = (su * u + du, sv * v + dv) (UvMapping::map, materials/mappings.rs:66-84):
+ * tex1 where floor(s) + floor(t) is even, tex2 where it is odd - point-sampled, as no ray differentials are carried. */
 enum { PM_MAT_DIFFUSE = 0, PM_MAT_DIELECTRIC = 1 };
+enum { PM_TEX_NONE = 0, PM_TEX_CHECKERBOARD = 1 };
 typedef struct PmMaterial {
     int32_t type;
-    PmSpectrum spectrum;             /* DIFFUSE: reflectance; DIELECTRIC: eta */
+    PmSpectrum spectrum;             /* DIFFUSE: reflectance (tex1); DIELECTRIC: eta */
     float u_roughness, v_roughness;  /* DIELECTRIC */
     int32_t remap_roughness;
+    int32_t texture;                 /* PM_TEX_* (DIFFUSE only) */
+    float su, sv, du, dv;            /* UvMapping */
+    PmSpectrum spectrum2;            /* tex2 */
 } PmMaterial;
 
 /* lights/{point,directional,infinite}.rs; `spectrum` is the light's DenselySampledSpectrum (471 floats) */
@@ -278,7 +292,7 @@ PM_STATIC_ASSERT(sizeof(PmSphere) == 152, "PmSphere");
 PM_STATIC_ASSERT(sizeof(PmAccelInfo) == 80, "PmAccelInfo");
 PM_STATIC_ASSERT(sizeof(PmCounters) == 48, "PmCounters");
 PM_STATIC_ASSERT(sizeof(PmSpectrum) == 32, "PmSpectrum");
-PM_STATIC_ASSERT(sizeof(PmMaterial) == 56, "PmMaterial");
+PM_STATIC_ASSERT(sizeof(PmMaterial) == 104, "PmMaterial");
 PM_STATIC_ASSERT(sizeof(PmLight) == 88, "PmLight");
 PM_STATIC_ASSERT(sizeof(PmMedium) == 48, "PmMedium");
 PM_STATIC_ASSERT(sizeof(PmCamera) == 136, "PmCamera");

@@ -41,6 +41,7 @@ def lib():
             "ora_add_sphere": (u32, [p, f, f, f, f, p, p, i]),
             "ora_add_patch_mesh": (u32, [p, p, u32, p, u32, i, i]),
             "ora_add_patch_mesh_n": (u32, [p, p, u32, p, u32, p, i, i]),
+            "ora_add_patch_mesh_uv": (u32, [p, p, u32, p, u32, p, p, i, i]),
             "ora_add_triangle_mesh": (u32, [p, p, u32, p, u32]),
             "ora_build": (i, [p, i, i]), "ora_scene_bounds": (None, [p, p]),
             "ora_trace_closest": (None, [p, p, u64, p, p, i, i]),
@@ -95,12 +96,14 @@ class Scene:
         a, b = _f32(rfo).reshape(16), _f32(ofr).reshape(16)
         return self._l.ora_add_sphere(self._h, radius, z_min, z_max, phi_max_deg, a.ctypes.data, b.ctypes.data, int(reverse))
 
-    def add_patch_mesh(self, positions, indices, reverse=False, swaps=False, normals=None):
+    def add_patch_mesh(self, positions, indices, reverse=False, swaps=False, normals=None, uv=None):
         pos = _f32(positions).reshape(-1, 3)
         idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 4)
         nrm = None if normals is None else _f32(normals).reshape(-1, 3)
-        return self._l.ora_add_patch_mesh_n(self._h, pos.ctypes.data, len(pos), idx.ctypes.data, len(idx),
-                                            None if nrm is None else nrm.ctypes.data, int(reverse), int(swaps))
+        tex = None if uv is None else _f32(uv).reshape(-1, 2)
+        return self._l.ora_add_patch_mesh_uv(self._h, pos.ctypes.data, len(pos), idx.ctypes.data, len(idx),
+                                             None if nrm is None else nrm.ctypes.data, None if tex is None else tex.ctypes.data,
+                                             int(reverse), int(swaps))
 
     def add_triangle_mesh(self, positions, indices):
         pos = _f32(positions).reshape(-1, 3)

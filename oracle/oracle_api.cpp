@@ -68,6 +68,8 @@ uint32_t ora_add_sphere(OraScene* s, float radius, float z_min, float z_max, flo
 // positions are already in render space (BilinearPatchMesh::new transforms them, bilinear_patch.rs:649-655)
 uint32_t ora_add_patch_mesh_n(OraScene* s, const float* pos, uint32_t n_vert, const uint32_t* idx4, uint32_t n_patch,
                               const float* normals, int reverse_orientation, int transform_swaps_handedness);
+uint32_t ora_add_patch_mesh_uv(OraScene* s, const float* pos, uint32_t n_vert, const uint32_t* idx4, uint32_t n_patch,
+                               const float* normals, const float* uv, int reverse_orientation, int transform_swaps_handedness);
 uint32_t ora_add_patch_mesh(OraScene* s, const float* pos, uint32_t n_vert, const uint32_t* idx4, uint32_t n_patch,
                             int reverse_orientation, int transform_swaps_handedness) {
     return ora_add_patch_mesh_n(s, pos, n_vert, idx4, n_patch, nullptr, reverse_orientation, transform_swaps_handedness);
@@ -76,6 +78,11 @@ uint32_t ora_add_patch_mesh(OraScene* s, const float* pos, uint32_t n_vert, cons
 // BilinearPatchMesh::new leaves them (bilinear_patch.rs:660-671); may be null
 uint32_t ora_add_patch_mesh_n(OraScene* s, const float* pos, uint32_t n_vert, const uint32_t* idx4, uint32_t n_patch,
                               const float* normals, int reverse_orientation, int transform_swaps_handedness) {
+    return ora_add_patch_mesh_uv(s, pos, n_vert, idx4, n_patch, normals, nullptr, reverse_orientation, transform_swaps_handedness);
+}
+// ... with per-vertex uv (BilinearPatchMesh.uv, bilinear_patch.rs:621-622; two floats per vertex, may be null)
+uint32_t ora_add_patch_mesh_uv(OraScene* s, const float* pos, uint32_t n_vert, const uint32_t* idx4, uint32_t n_patch,
+                               const float* normals, const float* uv, int reverse_orientation, int transform_swaps_handedness) {
     (void)n_vert;
     uint32_t first = s->next_id;
     for (uint32_t i = 0; i < n_patch; ++i) {
@@ -87,6 +94,13 @@ uint32_t ora_add_patch_mesh_n(OraScene* s, const float* pos, uint32_t n_vert, co
             auto N = [&](uint32_t k) { return V3(normals[3 * k], normals[3 * k + 1], normals[3 * k + 2]); };
             pt.has_normals = true;
             pt.n00 = N(idx4[4 * i]); pt.n10 = N(idx4[4 * i + 1]); pt.n01 = N(idx4[4 * i + 2]); pt.n11 = N(idx4[4 * i + 3]);
+        }
+        if (uv) {
+            pt.has_uv = true;
+            for (int k = 0; k < 2; ++k) {
+                pt.uv00[k] = uv[2 * idx4[4 * i] + k]; pt.uv10[k] = uv[2 * idx4[4 * i + 1] + k];
+                pt.uv01[k] = uv[2 * idx4[4 * i + 2] + k]; pt.uv11[k] = uv[2 * idx4[4 * i + 3] + k];
+            }
         }
         s->sc.patches.push_back(pt);
         s->sc.prims.push_back(Prim{PRIM_PATCH, (uint32_t)s->sc.patches.size() - 1, s->next_id++});
@@ -268,10 +282,13 @@ struct OraRenderer {
 OraRenderer* ora_renderer_create(OraScene* s, const OMaterial* mats, uint32_t n_mats, const uint32_t* prim_mat, uint32_t n_prims,
                                  const OLight* lights, uint32_t n_lights, const OCamera* cam, const OFilm* film) {
     OraRenderer* o = new OraRenderer();
-    o->tables.reserve(n_mats + n_lights + 16);
+    o->tables.reserve(2 * n_mats + n_lights + 16);
     o->r.scene = &s->sc;
     o->r.materials.assign(mats, mats + n_mats);
-    for (auto& m : o->r.materials) if (m.spec.table) m.spec.table = o->own(m.spec.table, 471);
+    for (auto& m : o->r.materials) {
+        if (m.spec.table) m.spec.table = o->own(m.spec.table, 471);
+        if (m.texture != TEX_NONE && m.spec2.table) m.spec2.table = o->own(m.spec2.table, 471);
+    }
     o->r.prim_material.assign(prim_mat, prim_mat + n_prims);
     o->r.lights.assign(lights, lights + n_lights);
     for (auto& l : o->r.lights) l.spectrum = o->own(l.spectrum, 471);

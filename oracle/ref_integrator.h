@@ -88,7 +88,10 @@ static inline Spec4 spectrum_sample(const OSpectrum& s, const Wavelengths& w) {
 
 // ---- flattened scene description ----------------------------------------------------------------
 enum { MAT_DIFFUSE = 0, MAT_DIELECTRIC = 1 };
-struct OMaterial { int32_t type; OSpectrum spec; float u_rough, v_rough; int32_t remap_roughness; };
+enum { TEX_NONE = 0, TEX_CHECKERBOARD = 1 };
+// texture / su sv du dv / spec2: the checkerboard extension (see include/pbrt_mi355.h PmMaterial)
+struct OMaterial { int32_t type; OSpectrum spec; float u_rough, v_rough; int32_t remap_roughness;
+                   int32_t texture; float su, sv, du, dv; OSpectrum spec2; };
 enum { LIGHT_POINT = 0, LIGHT_DIRECTIONAL = 1, LIGHT_UNIFORM_INFINITE = 2, LIGHT_DIFFUSE_AREA = 3 };
 struct OLight { int32_t type; float scale; float render_from_light[16]; const float* spectrum; uint32_t prim_id; int32_t two_sided; };
 // media/medium.rs:41-69 HomogeneousMedium: sigma_a / sigma_s densely sampled and already scaled by sigma_scale, HG asymmetry g;
@@ -300,7 +303,7 @@ struct FilterSamplerO {                                  // imaging/filter.rs:17
 };
 
 // ---- surface interaction (only the fields the integrators read) -------------------------------------
-struct SurfInt { V3fi pi; V3 n, ns, dpdus; uint32_t prim_id; };
+struct SurfInt { V3fi pi; V3 n, ns, dpdus; uint32_t prim_id; float u = 0.0f, v = 0.0f; };
 
 static inline SurfInt sphere_interaction(const Sphere& s, const Hit& h) {   // sphere.rs:371-442 + interaction.rs:99-131,354-369
     V3 ph = h.p_obj;
@@ -642,14 +645,28 @@ struct Renderer {
 
     SurfInt make_interaction(const Hit& h) const {
         const Prim& p = scene->prims[h.prim_slot];
-        return p.type == PRIM_SPHERE ? sphere_interaction(scene->spheres[p.index], h) : patch_interaction(scene->patches[p.index], h);
+        SurfInt si = p.type == PRIM_SPHERE ? sphere_interaction(scene->spheres[p.index], h) : patch_interaction(scene->patches[p.index], h);
+        si.u = h.u; si.v = h.v;
+        return si;
     }
     BSDF make_bsdf(const SurfInt& si, Wavelengths* w) const {   // material.rs:122-195
         const OMaterial& m = materials[prim_material[si.prim_id]];
         BSDF b;
         b.bxdf.type = m.type;
         if (m.type == MAT_DIFFUSE) {
-            Spec4 r = spectrum_sample(m.spec, *w);
+            bool second = false;
+            if (m.texture == TEX_CHECKERBOARD) {       // extension: point-sampled 2-D checkerboard over UvMapping::map (mappings.rs:66-84)
+                float s = si.u, t = si.v;
+                int pi = si.prim_id < prim_patch.size() ? prim_patch[si.prim_id] : -1;
+                if (pi >= 0 && scene->patches[pi].has_uv) {
+                    const Patch& pt = scene->patches[pi];
+                    s = lerpf(lerpf(pt.uv00[0], pt.uv01[0], si.v), lerpf(pt.uv10[0], pt.uv11[0], si.v), si.u);
+                    t = lerpf(lerpf(pt.uv00[1], pt.uv01[1], si.v), lerpf(pt.uv10[1], pt.uv11[1], si.v), si.u);
+                }
+                float ss = m.su * s + m.du, tt = m.sv * t + m.dv;
+                second = (((int)std::floor(ss) + (int)std::floor(tt)) & 1) != 0;
+            }
+            Spec4 r = spectrum_sample(second ? m.spec2 : m.spec, *w);
             for (int i = 0; i < NSP; ++i) r.v[i] = clampf(r.v[i], 0.0f, 1.0f);
             b.bxdf.refl = r; b.bxdf.eta = 1.0f; b.bxdf.tr = TrowbridgeReitz{0, 0};
         } else {

@@ -43,6 +43,8 @@ struct Patch {             // resolved corner positions + mesh flags
     bool flip_normal;      // reverse_orientation ^ transform_swaps_handedness
     bool has_normals = false;
     V3 n00, n10, n01, n11; // vertex normals in render space (BilinearPatchMesh::vertex_normals)
+    bool has_uv = false;
+    float uv00[2], uv10[2], uv01[2], uv11[2];   // vertex texture coordinates (BilinearPatchMesh.uv)
 };
 
 struct Prim {

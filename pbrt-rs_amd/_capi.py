@@ -47,7 +47,8 @@ class PmSpectrum(C.Structure):
 
 class PmMaterial(C.Structure):
     _fields_ = [("type", C.c_int32), ("spectrum", PmSpectrum), ("u_roughness", C.c_float), ("v_roughness", C.c_float),
-                ("remap_roughness", C.c_int32)]
+                ("remap_roughness", C.c_int32), ("texture", C.c_int32), ("su", C.c_float), ("sv", C.c_float),
+                ("du", C.c_float), ("dv", C.c_float), ("spectrum2", PmSpectrum)]
 
 
 class PmLight(C.Structure):
@@ -90,6 +91,7 @@ class PmRenderStats(C.Structure):
 
 PM_SPEC_CONSTANT, PM_SPEC_DENSE, PM_SPEC_RGB_ALBEDO, PM_SPEC_RGB_UNBOUNDED, PM_SPEC_RGB_ILLUMINANT, PM_SPEC_BLACKBODY = range(6)
 PM_MAT_DIFFUSE, PM_MAT_DIELECTRIC = 0, 1
+PM_TEX_NONE, PM_TEX_CHECKERBOARD = 0, 1
 PM_LIGHT_POINT, PM_LIGHT_DIRECTIONAL, PM_LIGHT_UNIFORM_INFINITE, PM_LIGHT_DIFFUSE_AREA = 0, 1, 2, 3
 PM_FILTER_BOX, PM_FILTER_TRIANGLE, PM_FILTER_GAUSSIAN = 0, 1, 2
 PM_INTEGRATOR_SIMPLE_PATH, PM_INTEGRATOR_RANDOM_WALK, PM_INTEGRATOR_VOL_PATH = 0, 1, 2
@@ -102,6 +104,7 @@ SYMBOLS = {
     "pm_last_error": (C.c_char_p, [_P]),
     "pm_add_spheres": (C.c_int, [_P, C.POINTER(PmSphere), C.c_uint32, C.POINTER(C.c_uint32)]),
     "pm_add_patch_mesh": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_int, C.c_int, C.POINTER(C.c_uint32)]),
+    "pm_add_patch_mesh_uv": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_uint32)]),
     "pm_add_triangle_mesh": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     "pm_clear_geometry": (C.c_int, [_P]),
     "pm_build_accel": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(PmAccelInfo)]),

@@ -34,7 +34,7 @@ class Sphere:
 class BilinearPatchMesh:
     """BilinearPatchMesh::new (src/shapes/bilinear_patch.rs:631-685); positions in render space."""
 
-    def __init__(self, positions, indices, reverse_orientation=False, transform_swaps_handedness=False, normals=None):
+    def __init__(self, positions, indices, reverse_orientation=False, transform_swaps_handedness=False, normals=None, uv=None):
         self.positions = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
         self.indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 4)
         # one shading normal per vertex, in render space, already negated when reverse_orientation (as the
@@ -42,6 +42,10 @@ class BilinearPatchMesh:
         self.normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
         if self.normals is not None and len(self.normals) != len(self.positions):
             raise ValueError("normals must hold one normal per vertex")
+        # one (u, v) texture coordinate per vertex (BilinearPatchMesh.uv), optional
+        self.uv = None if uv is None else np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+        if self.uv is not None and len(self.uv) != len(self.positions):
+            raise ValueError("uv must hold one coordinate pair per vertex")
         self.reverse_orientation = bool(reverse_orientation)
         self.transform_swaps_handedness = bool(transform_swaps_handedness)
 
@@ -94,9 +98,9 @@ class GpuAggregate:
                 s.reverse_orientation = 1 if p.reverse_orientation else 0
                 self._check(self._lib.pm_add_spheres(self._h, C.byref(s), 1, C.byref(first)))
             elif isinstance(p, BilinearPatchMesh):
-                self._check(self._lib.pm_add_patch_mesh(
+                self._check(self._lib.pm_add_patch_mesh_uv(
                     self._h, p.positions.ctypes.data, len(p.positions), p.indices.ctypes.data, len(p.indices),
-                    None if p.normals is None else p.normals.ctypes.data,
+                    None if p.normals is None else p.normals.ctypes.data, None if p.uv is None else p.uv.ctypes.data,
                     int(p.reverse_orientation), int(p.transform_swaps_handedness), C.byref(first)))
             elif isinstance(p, TriangleMesh):
                 self._check(self._lib.pm_add_triangle_mesh(

@@ -247,6 +247,10 @@ extern "C" int pm_add_spheres(pm_ctx* c, const PmSphere* s, uint32_t n, uint32_t
 
 extern "C" int pm_add_patch_mesh(pm_ctx* c, const float* pos, uint32_t n_vert, const uint32_t* idx4, uint32_t n_patch,
                                  const float* normals, int reverse_orientation, int swaps, uint32_t* first) {
+    return pm_add_patch_mesh_uv(c, pos, n_vert, idx4, n_patch, normals, nullptr, reverse_orientation, swaps, first);
+}
+extern "C" int pm_add_patch_mesh_uv(pm_ctx* c, const float* pos, uint32_t n_vert, const uint32_t* idx4, uint32_t n_patch,
+                                    const float* normals, const float* uv, int reverse_orientation, int swaps, uint32_t* first) {
     if (!c || !pos || (!idx4 && n_patch)) return fail(c, PM_ERR_INVALID, "pm_add_patch_mesh: null argument");
     for (uint64_t i = 0; i < (uint64_t)n_patch * 4; ++i)
         if (idx4[i] >= n_vert) return fail(c, PM_ERR_INVALID, "pm_add_patch_mesh: vertex index out of range");
@@ -257,6 +261,8 @@ extern "C" int pm_add_patch_mesh(pm_ctx* c, const float* pos, uint32_t n_vert, c
         for (int k = 0; k < 4; ++k) std::memcpy(h.p[k], pos + 3 * (size_t)idx4[4 * i + k], 12);
         h.has_normals = normals != nullptr;
         if (normals) for (int k = 0; k < 4; ++k) std::memcpy(h.n[k], normals + 3 * (size_t)idx4[4 * i + k], 12);
+        h.has_uv = uv != nullptr;
+        if (uv) for (int k = 0; k < 4; ++k) std::memcpy(h.uv[k], uv + 2 * (size_t)idx4[4 * i + k], 8);
         h.flip_normal = (reverse_orientation != 0) != (swaps != 0);
         h.prim_id = c->scene.next_prim_id++;
         h.bounds = box_of_points(h.p, 4);   // bilinear_patch.rs:176-181

@@ -20,6 +20,8 @@ struct HostPatch {
     float p[4][3];      // p00 p10 p01 p11
     float n[4][3];      // vertex normals (render space), valid when has_normals
     bool has_normals = false;
+    float uv[4][2];     // vertex texture coordinates, valid when has_uv
+    bool has_uv = false;
     bool flip_normal;
     uint32_t prim_id;
     Box bounds;

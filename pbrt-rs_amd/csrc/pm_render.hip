@@ -337,14 +337,32 @@ __device__ __forceinline__ uint32_t block_append(bool want, uint32_t* __restrict
 
 // SurfaceInteraction::get_bsdf (core/interaction.rs:186-215, materials/material.rs:122-195) at the sampled wavelengths;
 // may terminate the secondary wavelengths (pdfw is updated in registers and in the path state)
+// TEX: the scene has textured materials (compiled into the EXT shade kernel only); (u, v) = the hit's parametric coordinates
+template <bool TEX>
 __device__ __forceinline__ Bsdf make_bsdf(const SceneArrays& sc, const PathArrays& pa, const SurfInt& si, uint32_t prim_id,
-                                          const float* lam, uint32_t slot) {
+                                          const float* lam, uint32_t slot, float u = 0.0f, float v = 0.0f) {
     const DMaterial mat = sc.materials[sc.prim_material[prim_id]];
     Bsdf bsdf;
     bsdf.type = mat.type;
     if (mat.type == PM_MAT_DIFFUSE) {
+        bool second = false;
+        if (TEX && mat.texture == PM_TEX_CHECKERBOARD) {
+            // st of the hit: lerped vertex uv of a patch that carries them, else the shape's own (u, v); then UvMapping::map
+            f2 st; st.x = u; st.y = v;
+            const uint32_t ref = sc.prim_ref[prim_id];
+            if ((ref >> 30) != PM_PRIM_SPHERE) {
+                const DShadePatch& sp = sc.patches[ref & 0x3FFFFFFFu];
+                if (sp.flags & 4u) {
+                    const float* q = sc.pool + sp.uv_off;
+                    st.x = lerpf(lerpf(q[0], q[4], v), lerpf(q[2], q[6], v), u);
+                    st.y = lerpf(lerpf(q[1], q[5], v), lerpf(q[3], q[7], v), u);
+                }
+            }
+            const float s = mat.su * st.x + mat.du, t = mat.sv * st.y + mat.dv;
+            second = (((int)floorf(s) + (int)floorf(t)) & 1) != 0;
+        }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) bsdf.refl.v[c] = clampf(spectrum_at(sc.pool, mat.spec, lam[c]), 0.0f, 1.0f);
+        for (int c = 0; c < 4; ++c) bsdf.refl.v[c] = clampf(spectrum_at(sc.pool, second ? mat.spec2 : mat.spec, lam[c]), 0.0f, 1.0f);
         bsdf.eta = 1.0f; bsdf.tr.ax = 0.0f; bsdf.tr.ay = 0.0f;
     } else {
         bsdf.refl = spec_c(0.0f);
@@ -542,7 +560,7 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
             }
             if (depth != rc.max_depth) {
             depth++;
-            Bsdf bsdf = make_bsdf(sc, pa, si, prim_id, lam, slot);
+            Bsdf bsdf = make_bsdf<EXT>(sc, pa, si, prim_id, lam, slot, hv.z, hv.w);
             const f3 wo = -rd;
             // ---- next-event estimation (simple_path.rs:182-213)
             if (rc.sample_lights) {
@@ -679,7 +697,7 @@ __global__ __launch_bounds__(RB) void shade_rw_kernel(RenderConst rc, SceneArray
             SurfInt si;
             if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], ro, rd, hv.y);
             else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
-            const Bsdf bsdf = make_bsdf(sc, pa, si, prim_id, lam, slot);
+            const Bsdf bsdf = make_bsdf<false>(sc, pa, si, prim_id, lam, slot);
             const f3 wo = -rd;
             const uint2 r2 = pa.rng[g][i];
             rng.state = ((unsigned long long)r2.y << 32) | r2.x; rng.inc = rng_inc_of(rc, slot);
@@ -767,7 +785,7 @@ __global__ void film_image_kernel(const double* __restrict__ film, float* __rest
 // ========================================================================================== host side
 struct RenderState {
     // host copies of what the caller set
-    std::vector<PmMaterial> mats; std::vector<std::vector<float>> mat_tables;
+    std::vector<PmMaterial> mats; std::vector<std::vector<float>> mat_tables, mat_tables2; bool have_textures = false;
     std::vector<uint32_t> prim_mat;
     std::vector<PmLight> lights; std::vector<std::vector<float>> light_tables;
     bool have_medium = false; PmMedium medium{}; std::vector<float> med_sigma_a, med_sigma_s;
@@ -808,7 +826,7 @@ static bool spec_needs_table(int kind) { return kind == PM_SPEC_DENSE || kind ==
 extern "C" int pm_set_materials(pm_ctx* c, const PmMaterial* m, uint32_t n) {
     if (!c || (!m && n)) return fail(c, PM_ERR_INVALID, "pm_set_materials: null argument");
     RenderState* r = rs(c);
-    r->mats.assign(m, m + n); r->mat_tables.assign(n, {});
+    r->mats.assign(m, m + n); r->mat_tables.assign(n, {}); r->mat_tables2.assign(n, {});
     for (uint32_t i = 0; i < n; ++i) {
         if (m[i].type != PM_MAT_DIFFUSE && m[i].type != PM_MAT_DIELECTRIC) return fail(c, PM_ERR_INVALID, "pm_set_materials: unknown material type");
         if (m[i].spectrum.kind < PM_SPEC_CONSTANT || m[i].spectrum.kind > PM_SPEC_BLACKBODY) return fail(c, PM_ERR_INVALID, "pm_set_materials: unknown spectrum kind");
@@ -817,6 +835,16 @@ extern "C" int pm_set_materials(pm_ctx* c, const PmMaterial* m, uint32_t n) {
             r->mat_tables[i].assign(m[i].spectrum.table, m[i].spectrum.table + 471);
         }
         r->mats[i].spectrum.table = nullptr;
+        if (m[i].texture != PM_TEX_NONE && m[i].texture != PM_TEX_CHECKERBOARD) return fail(c, PM_ERR_INVALID, "pm_set_materials: unknown texture kind");
+        if (m[i].texture != PM_TEX_NONE) {
+            if (m[i].type != PM_MAT_DIFFUSE) return fail(c, PM_ERR_UNSUPPORTED, "pm_set_materials: textures are supported on diffuse materials only");
+            if (m[i].spectrum2.kind < PM_SPEC_CONSTANT || m[i].spectrum2.kind > PM_SPEC_BLACKBODY) return fail(c, PM_ERR_INVALID, "pm_set_materials: unknown spectrum kind (spectrum2)");
+            if (spec_needs_table(m[i].spectrum2.kind)) {
+                if (!m[i].spectrum2.table) return fail(c, PM_ERR_INVALID, "pm_set_materials: spectrum2 needs a 471-entry table");
+                r->mat_tables2[i].assign(m[i].spectrum2.table, m[i].spectrum2.table + 471);
+            }
+        }
+        r->mats[i].spectrum2.table = nullptr;
     }
     r->scene_dirty = true;
     return PM_OK;
@@ -959,11 +987,16 @@ static int upload_scene(pm_ctx* c, RenderState* r) {
     std::vector<float> pool;
     auto add_table = [&](const std::vector<float>& t) { int off = (int)pool.size(); pool.insert(pool.end(), t.begin(), t.end()); return off; };
     std::vector<DMaterial> dm(r->mats.size());
+    r->have_textures = false;
     for (size_t i = 0; i < dm.size(); ++i) {
         const PmMaterial& m = r->mats[i];
         dm[i].type = m.type; dm[i].ur = m.u_roughness; dm[i].vr = m.v_roughness; dm[i].remap = m.remap_roughness;
         dm[i].spec.kind = m.spectrum.kind; dm[i].spec.a = m.spectrum.a; dm[i].spec.b = m.spectrum.b; dm[i].spec.c = m.spectrum.c; dm[i].spec.d = m.spectrum.d;
         dm[i].spec.table = r->mat_tables[i].empty() ? -1 : add_table(r->mat_tables[i]);
+        dm[i].texture = m.texture; dm[i].su = m.su; dm[i].sv = m.sv; dm[i].du = m.du; dm[i].dv = m.dv;
+        dm[i].spec2.kind = m.spectrum2.kind; dm[i].spec2.a = m.spectrum2.a; dm[i].spec2.b = m.spectrum2.b; dm[i].spec2.c = m.spectrum2.c; dm[i].spec2.d = m.spectrum2.d;
+        dm[i].spec2.table = r->mat_tables2[i].empty() ? -1 : add_table(r->mat_tables2[i]);
+        if (m.texture != PM_TEX_NONE) r->have_textures = true;
     }
     std::vector<DLight> dl(r->lights.size());
     std::vector<int> inf;
@@ -1015,6 +1048,10 @@ static int upload_scene(pm_ctx* c, RenderState* r) {
         if (p.has_normals) {
             d.flags |= 2u; d.nrm_off = (uint32_t)pool.size();
             pool.insert(pool.end(), &p.n[0][0], &p.n[0][0] + 12);
+        }
+        if (p.has_uv) {
+            d.flags |= 4u; d.uv_off = (uint32_t)pool.size();
+            pool.insert(pool.end(), &p.uv[0][0], &p.uv[0][0] + 8);
         }
         ref[p.prim_id] = ((uint32_t)PM_PRIM_PATCH << 30) | (uint32_t)sp.size(); sp.push_back(d);
     }
@@ -1107,6 +1144,8 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     const size_t max_paths = npix_pad * (size_t)s_per_pass;
     if (max_paths > 0x7FFFFFFFull) return fail(c, PM_ERR_INVALID, "pm_render: window too large for one pass");
     const bool random_walk = p->integrator == PM_INTEGRATOR_RANDOM_WALK;
+    if (random_walk && (r->have_textures || r->have_area_lights))
+        return fail(c, PM_ERR_UNSUPPORTED, "pm_render: the RandomWalk kernel supports neither textures nor area lights (extensions of SimplePath / VolPath)");
     if ((rcode = ensure_paths(c, r, max_paths, p->max_depth, random_walk))) return rcode;
     if ((rcode = ensure_defer(c, max_paths))) return rcode;
     const bool has_spheres = !c->scene.spheres.empty();
@@ -1122,7 +1161,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     rc.medium_on = (p->integrator == PM_INTEGRATOR_VOL_PATH && r->have_medium) ? 1 : 0;
     rc.med_sigma_a = r->med_off_a; rc.med_sigma_s = r->med_off_s; rc.med_g = r->medium.g;
     std::memcpy(rc.med_bounds, r->medium.bounds, sizeof(rc.med_bounds));
-    const bool shade_ext = rc.medium_on || r->have_area_lights;
+    const bool shade_ext = rc.medium_on || r->have_area_lights || r->have_textures;
     {   // SceneData::new -> light.preprocess(scene_bounds): Bounds3f::bounding_sphere (core/bounds.rs:588-597)
         const pm::Box& b = c->accel.bounds;
         float ctr[3], d2 = 0.0f; bool inside = true;

@@ -101,7 +101,7 @@ PMD float rng_uniform(Rng* r) {
 
 // ---------------------------------------------------------------------------------------- spectra
 struct DSpectrum { int kind; float a, b, c, d; int table; };   // table: offset into the float pool
-struct DMaterial { int type; DSpectrum spec; float ur, vr; int remap; };
+struct DMaterial { int type; DSpectrum spec; float ur, vr; int remap; int texture; float su, sv, du, dv; DSpectrum spec2; };
 struct DLight { int type; float scale; float m[12]; int table; uint32_t prim_id; int two_sided; };
 
 PMD float dense_at(const float* __restrict__ pool, int table, float lambda) {
@@ -213,7 +213,7 @@ PMD float sample_tent(float u, float r) {
 
 // ---------------------------------------------------------------------------------------- render constants
 struct DFilter { int kind; float rx, ry; int nx, ny; int vals, cond_cdf, cond_int, marg_func, marg_cdf; float marg_int; };
-struct DShadePatch { float p[12]; uint32_t flags; uint32_t nrm_off; uint32_t pad[2]; };     // 64 B; flags bit 0 flip normal, bit 1 vertex normals (12 floats at pool[nrm_off])
+struct DShadePatch { float p[12]; uint32_t flags; uint32_t nrm_off; uint32_t uv_off; uint32_t pad; };     // 64 B; flags bit 0 flip normal, bit 1 vertex normals (12 floats at pool[nrm_off]), bit 2 vertex uv (8 floats at pool[uv_off]: uv00 uv10 uv01 uv11)
 struct DShadeSphere { float rfo[12]; float ofr[12]; float radius, z_min, z_max, phi_max, th_min, th_max; uint32_t flags; uint32_t pad; };  // 128 B
 
 struct RenderConst {

@@ -185,6 +185,14 @@ def diffuse(reflectance):
     return {"type": PM_MAT_DIFFUSE, "spectrum": reflectance, "u_roughness": 0.0, "v_roughness": 0.0, "remap": False}
 
 
+def checkerboard_diffuse(tex1, tex2, su=1.0, sv=1.0, du=0.0, dv=0.0):
+    """DiffuseMaterial whose reflectance is a 2-D checkerboard texture (extension, scenes/test.pbrt:26-30): tex1 where
+    floor(su u + du) + floor(sv v + dv) is even, tex2 where it is odd"""
+    m = diffuse(tex1)
+    m.update(texture=_capi.PM_TEX_CHECKERBOARD, spectrum2=tex2, su=float(su), sv=float(sv), du=float(du), dv=float(dv))
+    return m
+
+
 def dielectric(eta, u_roughness=0.0, v_roughness=0.0, remap_roughness=False):
     """DielectricMaterial::new(u_rough, v_rough, remap, eta)"""
     return {"type": PM_MAT_DIELECTRIC, "spectrum": eta, "u_roughness": float(u_roughness),
@@ -240,6 +248,17 @@ class SceneDescription:
                 arr[i].spectrum.table = t.ctypes.data_as(C.POINTER(C.c_float))
             arr[i].u_roughness, arr[i].v_roughness = m["u_roughness"], m["v_roughness"]
             arr[i].remap_roughness = int(m["remap"])
+            arr[i].texture = int(m.get("texture", 0))
+            if arr[i].texture:
+                arr[i].su, arr[i].sv, arr[i].du, arr[i].dv = m["su"], m["sv"], m["du"], m["dv"]
+                s2 = m["spectrum2"]
+                arr[i].spectrum2.kind = s2["kind"]
+                for k in "abcd":
+                    setattr(arr[i].spectrum2, k, float(s2.get(k, 0.0)))
+                if "table" in s2:
+                    t2 = _f32(s2["table"])
+                    self._keep.append(t2)
+                    arr[i].spectrum2.table = t2.ctypes.data_as(C.POINTER(C.c_float))
         return arr
 
     def c_lights(self):

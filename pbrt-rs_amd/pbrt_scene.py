@@ -10,8 +10,12 @@ where the reference has none yet):
   Sampler (pixelsamples)   PixelFilter "gaussian" (radius, sigma)   Integrator "simplepath"|"path"|"volpath"|"randomwalk" (maxdepth)
   LightSource "infinite" (L, scale) | "distant" (from, to, L, scale) | "point" (from, I, scale)
   Material "diffuse" (reflectance) | "dielectric" (eta, roughness, uroughness, vroughness, remaproughness)
-  Texture <name> "spectrum"|"float" "constant" (value)     (other texture classes are rejected: the reference only has constants)
-  Shape "sphere" (radius, zmin, zmax, phimax) | "bilinearmesh" (P, indices, N) | "trianglemesh" (P, indices)
+  Texture <name> "spectrum"|"float" "constant" (value) | "spectrum" "checkerboard" (uscale, vscale, udelta, vdelta, tex1, tex2)
+          (other texture classes are rejected; the checkerboard is an extension for scenes/test.pbrt, point-sampled)
+  Shape "sphere" (radius, zmin, zmax, phimax) | "bilinearmesh" (P, indices, N, uv) | "trianglemesh" (P, indices)
+Substitutions are made LOUDLY: every one is appended to settings["warnings"] (the reference has one sampler and no
+MIS / volumetric integrator): Sampler "halton"/"sobol"/... -> independent (same pixelsamples and seed);
+Integrator "path" -> simplepath; "volpath" -> VolPath, which without a medium in the file equals simplepath.
 Spectrum-valued parameters: "rgb X" [r g b], "blackbody X" T, "float X" v, "spectrum X" v (constant).
 Anything else raises PbrtSceneError naming the directive: nothing is silently dropped.
 """
@@ -131,7 +135,9 @@ def load_pbrt(text, spectra=None):
     """Parse scene text -> (SceneDescription, settings dict with integrator / max_depth / spp / seed)."""
     sp = spectra or host.Spectra()
     sd = host.SceneDescription()
-    settings = {"integrator": "simplepath", "max_depth": 5, "spp": 16, "seed": 0, "sample_lights": True, "sample_bsdf": True}
+    settings = {"integrator": "simplepath", "max_depth": 5, "spp": 16, "seed": 0, "sample_lights": True, "sample_bsdf": True,
+                "warnings": [], "filename": None}
+    warn = settings["warnings"].append
     st, stack = _State(), []
     named_textures = {}
     camera = None
@@ -190,10 +196,20 @@ def load_pbrt(text, spectra=None):
             camera = {"camera_from_world": st.ctm, "fov": _float(p, "fov", 90.0), "lens": _float(p, "lensradius", 0.0),
                       "focal": _float(p, "focaldistance", 1e6)}
         elif name == "Film":
+            if args and args[0] != "rgb":
+                raise PbrtSceneError(f'Film "{args[0]}" is not supported (the reference has RGBFilm only, camera/film.rs:24-28)')
             film["res"] = (int(_float(p, "xresolution", 1280)), int(_float(p, "yresolution", 720)))
+            if "filename" in p:
+                settings["filename"] = p["filename"][1][0].strip('"')
+                if not settings["filename"].lower().endswith(".exr"):
+                    warn(f'Film filename "{settings["filename"]}": the reference writes OpenEXR only (imaging/image.rs:48-57); '
+                         f"use write_exr with an .exr name")
         elif name == "Sampler":
             settings["spp"] = int(_float(p, "pixelsamples", 16))
             settings["seed"] = int(_float(p, "seed", 0))
+            if args and args[0] != "independent":
+                warn(f'Sampler "{args[0]}" -> "independent": the reference has IndependentSampler only (sampling/sampler.rs:10-14); '
+                     f'{settings["spp"]} samples per pixel kept')
         elif name == "PixelFilter":
             if args[0] != "gaussian":
                 raise PbrtSceneError(f'PixelFilter "{args[0]}" is not supported by the GPU film sampler')
@@ -203,7 +219,13 @@ def load_pbrt(text, spectra=None):
             kind = args[0]
             if kind not in ("simplepath", "path", "volpath", "randomwalk"):
                 raise PbrtSceneError(f'Integrator "{kind}" is not supported')
-            settings["integrator"] = "randomwalk" if kind == "randomwalk" else "simplepath"
+            settings["integrator"] = {"randomwalk": "randomwalk", "volpath": "volpath"}.get(kind, "simplepath")
+            if kind == "path":
+                warn('Integrator "path" -> "simplepath": the reference has no MIS / Russian-roulette path integrator '
+                     "(integrators/base.rs:26-30)")
+            if kind == "volpath":
+                warn('Integrator "volpath" -> VolPath extension (SimplePath + homogeneous medium); this file declares no medium '
+                     "(MakeNamedMedium / MediumInterface are not ingested), so it renders as simplepath")
             settings["max_depth"] = int(_float(p, "maxdepth", 5))
             settings["sample_lights"] = _bool(p, "samplelights", True)
             settings["sample_bsdf"] = _bool(p, "samplebsdf", True)
@@ -214,10 +236,18 @@ def load_pbrt(text, spectra=None):
             st.ctm = host.Transform.IDENTITY
         elif name == "Texture":
             tname, ttype, tclass = args[0], args[1], args[2]
-            if tclass != "constant":
-                raise PbrtSceneError(f'Texture class "{tclass}" is not supported (the reference has only constant textures, '
-                                     f"materials/textures.rs:63-84)")
-            named_textures[tname] = spectrum_param(p, "value") or ("const", np.float32(1.0))
+            if tclass == "constant":
+                named_textures[tname] = spectrum_param(p, "value") or ("const", np.float32(1.0))
+            elif tclass == "checkerboard" and ttype == "spectrum":
+                if int(_float(p, "dimension", 2)) != 2:
+                    raise PbrtSceneError("only the 2-D checkerboard is supported")
+                named_textures[tname] = ("checker", (spectrum_param(p, "tex1") or ("const", np.float32(1.0)),
+                                                     spectrum_param(p, "tex2") or ("const", np.float32(0.0)),
+                                                     _float(p, "uscale", 1.0), _float(p, "vscale", 1.0),
+                                                     _float(p, "udelta", 0.0), _float(p, "vdelta", 0.0)))
+            else:
+                raise PbrtSceneError(f'Texture class "{tclass}" ({ttype}) is not supported (the reference has only constant '
+                                     f"textures, materials/textures.rs:63-84; the spectrum checkerboard is this library's extension)")
         elif name == "Material":
             st.material = (args[0], p)
         elif name == "LightSource":
@@ -290,12 +320,18 @@ def load_pbrt(text, spectra=None):
             return material_ids[key]
         if kind == "diffuse":
             spec = spectrum_param(p, "reflectance") or ("const", f32(0.5))
-            if spec[0] == "rgb":
-                m = host.diffuse(sp.rgb_albedo(spec[1]))
-            elif spec[0] == "const":
-                m = host.diffuse(host.constant_spectrum(float(spec[1])))
+
+            def albedo(s):
+                if s[0] == "rgb":
+                    return sp.rgb_albedo(s[1])
+                if s[0] == "const":
+                    return host.constant_spectrum(float(s[1]))
+                raise PbrtSceneError("diffuse reflectance must be rgb, a constant, or a checkerboard of those")
+            if spec[0] == "checker":
+                t1, t2, su, sv, du, dv = spec[1]
+                m = host.checkerboard_diffuse(albedo(t1), albedo(t2), float(su), float(sv), float(du), float(dv))
             else:
-                raise PbrtSceneError("diffuse reflectance must be rgb or a constant")
+                m = host.diffuse(albedo(spec))
         elif kind == "dielectric":
             eta = spectrum_param(p, "eta") or ("const", f32(1.5))
             if eta[0] != "const":
@@ -337,8 +373,13 @@ def load_pbrt(text, spectra=None):
                     nrm = np.stack([n[:, 0] * mi[0, c] + n[:, 1] * mi[1, c] + n[:, 2] * mi[2, c] for c in range(3)], axis=1).astype(f32)
                     if reverse:
                         nrm = -nrm
+                uv = None
+                if "uv" in p or "st" in p:
+                    uv = np.asarray(_floats(p, "uv" if "uv" in p else "st"), f32).reshape(-1, 2)
+                    if len(uv) != len(P):
+                        raise PbrtSceneError('"point2 uv" needs one pair per vertex')
                 det = np.linalg.det(t.m[:3, :3].astype(np.float64))
-                sd.prims.append(BilinearPatchMesh(pos, idx, reverse, bool(det < 0), normals=nrm))
+                sd.prims.append(BilinearPatchMesh(pos, idx, reverse, bool(det < 0), normals=nrm, uv=uv))
             else:
                 sd.prims.append(TriangleMesh(pos, idx))
             prim_mats.extend([mid] * len(idx))
@@ -355,8 +396,8 @@ def load_pbrt_file(path, spectra=None):
 
 def integrator_from(sd, settings, device_id=0):
     """WavefrontIntegrator for a parsed scene"""
-    from ._capi import PM_INTEGRATOR_RANDOM_WALK, PM_INTEGRATOR_SIMPLE_PATH
+    from ._capi import PM_INTEGRATOR_RANDOM_WALK, PM_INTEGRATOR_SIMPLE_PATH, PM_INTEGRATOR_VOL_PATH
     from .integrator import WavefrontIntegrator
-    kind = PM_INTEGRATOR_RANDOM_WALK if settings["integrator"] == "randomwalk" else PM_INTEGRATOR_SIMPLE_PATH
+    kind = {"randomwalk": PM_INTEGRATOR_RANDOM_WALK, "volpath": PM_INTEGRATOR_VOL_PATH}.get(settings["integrator"], PM_INTEGRATOR_SIMPLE_PATH)
     return WavefrontIntegrator(settings["max_depth"], settings["sample_lights"], settings["sample_bsdf"], sd, settings["spp"],
                                seed=settings["seed"], device_id=device_id, integrator=kind)

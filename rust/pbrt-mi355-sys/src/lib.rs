@@ -32,6 +32,9 @@ pub const PM_SPEC_BLACKBODY: i32 = 5;
 pub const PM_MAT_DIFFUSE: i32 = 0;
 pub const PM_MAT_DIELECTRIC: i32 = 1;
 
+pub const PM_TEX_NONE: i32 = 0;
+pub const PM_TEX_CHECKERBOARD: i32 = 1;
+
 pub const PM_LIGHT_POINT: i32 = 0;
 pub const PM_LIGHT_DIRECTIONAL: i32 = 1;
 pub const PM_LIGHT_UNIFORM_INFINITE: i32 = 2;
@@ -127,6 +130,12 @@ pub struct PmMaterial {
     pub u_roughness: f32,
     pub v_roughness: f32,
     pub remap_roughness: i32,
+    pub texture: i32,
+    pub su: f32,
+    pub sv: f32,
+    pub du: f32,
+    pub dv: f32,
+    pub spectrum2: PmSpectrum,
 }
 
 #[repr(C)]
@@ -214,6 +223,7 @@ extern "C" {
     pub fn pm_last_error(ctx: *mut pm_ctx) -> *const c_char;
     pub fn pm_add_spheres(ctx: *mut pm_ctx, spheres: *const PmSphere, n: u32, first_prim_id: *mut u32) -> i32;
     pub fn pm_add_patch_mesh(ctx: *mut pm_ctx, pos_xyz: *const f32, n_vert: u32, idx4: *const u32, n_patch: u32, normals_or_null: *const f32, reverse_orientation: i32, transform_swaps_handedness: i32, first_prim_id: *mut u32) -> i32;
+    pub fn pm_add_patch_mesh_uv(ctx: *mut pm_ctx, pos_xyz: *const f32, n_vert: u32, idx4: *const u32, n_patch: u32, normals_or_null: *const f32, uv_or_null: *const f32, reverse_orientation: i32, transform_swaps_handedness: i32, first_prim_id: *mut u32) -> i32;
     pub fn pm_add_triangle_mesh(ctx: *mut pm_ctx, pos_xyz: *const f32, n_vert: u32, idx3: *const u32, n_tri: u32, first_prim_id: *mut u32) -> i32;
     pub fn pm_clear_geometry(ctx: *mut pm_ctx) -> i32;
     pub fn pm_build_accel(ctx: *mut pm_ctx, split_method: i32, max_prims_in_node: i32, info_or_null: *mut PmAccelInfo) -> i32;

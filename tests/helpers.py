@@ -12,7 +12,7 @@ def oracle_scene_from(sd, ora, split=None):
         if isinstance(p, pmod.Sphere):
             sc.add_sphere(p.radius, p.z_min, p.z_max, p.phi_max, p.render_from_object, p.object_from_render, p.reverse_orientation)
         elif isinstance(p, pmod.BilinearPatchMesh):
-            sc.add_patch_mesh(p.positions, p.indices, p.reverse_orientation, p.transform_swaps_handedness, normals=p.normals)
+            sc.add_patch_mesh(p.positions, p.indices, p.reverse_orientation, p.transform_swaps_handedness, normals=p.normals, uv=p.uv)
         else:
             sc.add_triangle_mesh(p.positions, p.indices)
     sc.build(split if split is not None else ora.SPLIT_MIDDLE, 255)

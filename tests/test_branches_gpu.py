@@ -279,3 +279,15 @@ def test_c4_shaped_scene_bitwise(pm, ora):
     frac, tot = _bit_equal(pm, ora, sd, spp)
     _report("C4-shaped, 16 384 triangles", frac, tot)
     assert frac >= 0.9999
+
+
+def test_checkerboard_texture_bitwise(pm, ora):
+    """the checkerboard extension without vertex uv (st = the patch's own (u, v)), offsets and anisotropic scales, on a
+    multi-patch mesh with an rgb / constant pair of reflectances"""
+    res, spp = (64, 64), 8
+    sd = pm.scenes.shading_normal_scene(res)
+    sp = pm.host.Spectra()
+    sd.materials[1] = pm.host.checkerboard_diffuse(sp.rgb_albedo((0.8, 0.3, 0.2)), pm.host.constant_spectrum(0.15), 3.0, 5.0, 0.25, -0.4)
+    frac, tot = _bit_equal(pm, ora, sd, spp)
+    _report("checkerboard on a patch mesh without vertex uv", frac, tot)
+    assert frac >= 0.9999
