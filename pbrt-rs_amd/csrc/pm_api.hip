@@ -33,7 +33,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR(ANY, MIXED) void trace_ke
                                                             uint4* __restrict__ defer_list, uint32_t defer_cap,
                                                             unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TRACE_BLOCK];
-    __shared__ uint32_t cand[2 * PM_CAND_MAX * TRACE_BLOCK];     // units, then t lower bounds
+    __shared__ uint32_t cand[PM_CAND_WORDS(ANY, COUNT, MIXED) * TRACE_BLOCK];     // units, then t lower bounds, then the ring of parked leaves
     pmd::TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, pmd::Ray* ray) -> bool {
         const float4* rp = reinterpret_cast<const float4*>(rays + i);

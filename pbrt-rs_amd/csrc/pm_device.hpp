@@ -419,6 +419,22 @@ struct SlowWriter {
 };
 
 #define PM_CAND_MAX 4
+// Deferred leaf tests (timed closest-hit walks of triangle-only scenes).  A node step finds a leaf for ~1 lane in 7, but the
+// wave pays a whole pre-filter trip (~100 instructions + the record fetch) as soon as ONE lane has one, so testing leaves
+// inside the step ran the leaf code at ~10 % lane utilisation (PMC: 0.53 active lanes over the whole walk).  Instead a lane
+// parks the leaves it meets in a small ring (PM_PEND_MAX entries, LDS) and the wave runs ONE pre-filter trip when at least
+// PM_PEND_FLUSH walking lanes have something parked (or a ring is full); lanes whose walk has ended drain their ring in the
+// refill phase, where >= `refill` lanes work together.  Culling (tcull) learns of a certain hit a few steps later, i.e. a
+// ray may visit a few more nodes: results do not change (the exact round decides them), but the walk of a ray now depends
+// on its wave, so the COUNTING kernels (the deterministic counters of SURVEY 8d) keep testing leaves at once.
+#ifndef PM_PEND_MAX
+#define PM_PEND_MAX 4          /* 0 disables; power of two */
+#endif
+// words of the per-lane candidate array a kernel instance needs (the ring exists only where the walk parks leaves)
+#define PM_CAND_WORDS(ANY, COUNT, MIXED) (2 * PM_CAND_MAX + ((ANY) || (COUNT) || (MIXED) ? 0 : PM_PEND_MAX))
+#ifndef PM_PEND_FLUSH
+#define PM_PEND_FLUSH 24
+#endif
 // The flat sweep meets candidates in table order, not front to back, so now and then a ray collects more than 4; a wave
 // makes as many exact-test trips as its busiest lane has candidates, so those rays are NOT given a deeper queue (measured:
 // depth 6 costs 14 %) but handed to the slow list.
@@ -477,6 +493,8 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
     bool sure_any = false;
 #define PM_SURE (ANY ? sure_any : (tcull < ray.tmax))
     uint32_t qn = 0;
+    constexpr bool DEFERL = PM_PEND_MAX > 0 && !ANY && !COUNT && !MIXED;
+    uint32_t np = 0, ph = 0;                              // parked leaves: count, ring head
     uint32_t sph0 = 0xFFFFFFFFu, sph1 = 0xFFFFFFFFu;      // spheres that passed the pre-filter (deferred to sphere_fix)
     int sp = 0;
     uint2 cur = make_uint2(0u, 0u);
@@ -484,11 +502,36 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
     uint2 spill[PM_SPILL_STACK];
 
     auto start_walk = [&]() {
-        tmax = ray.tmax; tcull = ray.tmax; sure_any = false; found = false; qn = 0; sp = 0; steps = 0;
+        tmax = ray.tmax; tcull = ray.tmax; sure_any = false; found = false; qn = 0; sp = 0; steps = 0; np = 0; ph = 0;
         sph0 = 0xFFFFFFFFu; sph1 = 0xFFFFFFFFu;
         hit.prim_id = 0xFFFFFFFFu; hit.t = ray.tmax; hit.u = 0.0f; hit.v = 0.0f;
         cur = make_uint2(0u, (1u << 8) | perm8(1u, oct));     // pseudo group holding only the root
         active = true;
+    };
+
+    // pre-filter of one parked triangle (DEFERL): the triangle branch of the leaf loop below, for a unit popped from the ring
+    auto drain_one = [&]() {
+        const uint32_t unit = cand[(2 * PM_CAND_MAX + (ph & (PM_PEND_MAX > 0 ? PM_PEND_MAX - 1 : 0))) * stride];
+        ++ph; --np;
+        const uint4* r = prims + unit;
+        const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
+        const f3 p00 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
+        const f3 p10 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
+        const f3 p01 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
+        float th, tl;
+        const int cls = tri_prefilter(ray.o, ray.d, R, D, p00, p10, p01, tcull, &th, &tl);
+        if (cls != 0) {
+            if (cls == 2) tcull = th;
+            if (qn < PM_CAND_MAX) {
+                cand[qn * stride] = unit; cand[(PM_CAND_MAX + qn) * stride] = __float_as_uint(tl);
+                ++qn;
+            } else {                                  // candidate queue full: the exact test at once
+                float t, u, v;
+                if (intersect_tri_exact(ray.o, ray.d, tmax, p00, p10, p01, &t, &u, &v)) {
+                    tmax = t; found = true; hit.prim_id = r2.y; hit.t = t; hit.u = u; hit.v = v;
+                }
+            }
+        }
     };
 
     // Work items are reserved from the global counter in chunks (one atomic per chunk, not per refill) sized so that every
@@ -507,6 +550,12 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
         if (n_idle == 64u || ((more || wnext < wend) && n_idle >= refill)) {
             // ---- lanes whose walk has ended: exact tests of the queued triangles, in the order they were met
             bool defer = false;
+            if (DEFERL) {        // lanes whose walk has ended: what is still parked goes through the pre-filter now, together
+                for (int k = 0; k < PM_PEND_MAX; ++k) {
+                    if (!__any(finished && np > 0u)) break;
+                    if (finished && np > 0u) drain_one();
+                }
+            }
             if (finished) {
                 for (uint32_t qj = 0; qj < PM_CAND_MAX; ++qj) {
                     if (qj >= qn || (ANY && found)) continue;
@@ -603,8 +652,8 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                     ++sp;
                 }
                 // ---- fetch the 80-byte node (5 x 16 B)
-                const uint4* np = reinterpret_cast<const uint4*>(nodes + nidx);
-                const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+                const uint4* nq = reinterpret_cast<const uint4*>(nodes + nidx);
+                const uint4 n0 = nq[0], n1 = nq[1], n2 = nq[2], n3 = nq[3], n4 = nq[4];
                 if (COUNT) ctr->nodes++;
                 const uint32_t imask = n0.w >> 24;
                 // ---- pre-scaled slab test: t = q * (scale/d) + (origin - o)/d, margins folded into the addends
@@ -679,6 +728,11 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                             // triangle record: v0 v1 v2 id ; patch record: p00 p10 p01 p11 id
                             const bool is_tri = ptype == PM_PRIM_TRI;
                             const uint32_t unit = pbase + (off + j) * (is_tri ? PM_UNITS_TRI : PM_UNITS_PATCH);
+                            if (DEFERL && !exact_mode && np < PM_PEND_MAX) {        // park it (triangle-only scene)
+                                cand[(2 * PM_CAND_MAX + ((ph + np) & (PM_PEND_MAX > 0 ? PM_PEND_MAX - 1 : 0))) * stride] = unit;
+                                ++np;
+                                continue;
+                            }
                             const uint4* r = prims + unit;
                             const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
                             const f3 p00 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
@@ -725,6 +779,13 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                 }
                 // ---- descend into the interior children that were hit
                 cur = make_uint2(n1.x, (imask << 8) | PM_PERM8(hits & imask));
+            }
+        }
+        if (DEFERL) {       // one pre-filter trip for the walking lanes, when enough of them have a leaf parked
+            const bool have = active && np > 0u;
+            const unsigned long long hm = __ballot(have);
+            if (hm != 0ull && ((uint32_t)__popcll(hm) >= PM_PEND_FLUSH || __any(active && np == PM_PEND_MAX))) {
+                if (have) drain_one();
             }
         }
     }

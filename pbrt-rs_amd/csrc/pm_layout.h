@@ -67,8 +67,10 @@ struct PmFlatScene { const PmFlatTri* tris; const uint32_t* units; uint32_t n_sp
 
 #define PM_MAX_LEAF 4
 #ifndef PM_LDS_STACK
-#define PM_LDS_STACK 8       // per-lane entries kept in LDS (8 KB per 128-lane block: with the candidate queue and the
-                             // permutation table a block takes 14 KB, so the 10 blocks = 5 waves per SIMD that the kernels'
-                             // registers allow fit the CU's 160 KB; 12 entries held the walk to 4 waves per SIMD)
+#define PM_LDS_STACK 6       // per-lane entries kept in LDS (6 KB per 128-lane block: with the candidate queue, the ring of
+                             // parked leaves and the permutation table a block takes 14 KB, so the 10 blocks = 5 waves per
+                             // SIMD that the kernels' registers allow fit the CU's 160 KB.  Measured with the ring in place
+                             // (profiles/r02/ab_deferl.log): 8 entries = 16 KB 57 ms, 6 = 54 ms, 5 = 56 ms, 4 = 59 ms on the
+                             // C4-small closest-hit launches; 12 entries held the walk to 4 waves per SIMD)
 #endif
 #define PM_SPILL_STACK (48 - PM_LDS_STACK)    // per-lane overflow entries (private memory)

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR(false, MIXED) void closest_kernel(
                                                      const uint32_t* __restrict__ count, uint32_t* __restrict__ work, uint32_t refill,
                                                      uint4* __restrict__ defer_list, uint32_t defer_cap, unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
-    __shared__ uint32_t cand[2 * PM_CAND_MAX * TB];     // units, then t lower bounds
+    __shared__ uint32_t cand[PM_CAND_WORDS(false, COUNT, MIXED) * TB];     // units, then t lower bounds, then the ring of parked leaves
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
         const float4 d = pa.rd[g][i];
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR(true, MIXED) void shadow_kernel(Sc
                                                     uint32_t* __restrict__ work, uint32_t refill, uint4* __restrict__ defer_list, uint32_t defer_cap,
                                                     unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
-    __shared__ uint32_t cand[2 * PM_CAND_MAX * TB];     // units, then t lower bounds
+    __shared__ uint32_t cand[PM_CAND_WORDS(true, COUNT, MIXED) * TB];     // units, then t lower bounds, then the ring of parked leaves
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
         const float4 o = pa.sh_o[i], d = pa.sh_d[i];
