@@ -109,8 +109,8 @@ public:
     }
     float photometric(const std::vector<float>& table) const { return pmh_photometric(cie_y.data(), table.data()); }
     // RGBColorSpace::to_rgb_coeffs for sRGB (color/color_space.rs:110-184): trilinear lookup in the 3 x 64^3 table.  The
-    // reference reads it from src/util/rgbspectrum_srgb.txt, missing upstream; it is regenerated once
-    // (pmh_rgb_table_generate) and cached as `rgbspectrum_srgb.bin` next to the CIE tables.
+    // reference reads it from src/util/rgbspectrum_srgb.txt, missing upstream; it is regenerated once with the published
+    // generator's recipe (pmh_rgb_table_generate) and cached as `rgbspectrum_srgb.bin` next to the CIE tables.
     std::array<float, 3> rgb_coeffs(float r, float g, float b) const {
         const float rgb[3] = {std::fmax(r, 0.0f), std::fmax(g, 0.0f), std::fmax(b, 0.0f)};
         std::array<float, 3> c{};
@@ -147,16 +147,16 @@ private:
         const std::string path = (slash == std::string::npos ? std::string() : tables_bin.substr(0, slash + 1)) + "rgbspectrum_srgb.bin";
         if (std::FILE* f = std::fopen(path.c_str(), "rb")) {
             char magic[8];
-            const bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "PMRGBT1\0", 8) == 0 &&
+            const bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "PMRGBT2\0", 8) == 0 &&
                             std::fread(z_nodes_.data(), 4, 64, f) == 64 && std::fread(coeffs_.data(), 4, n, f) == n;
             std::fclose(f);
             if (ok) return;
         }
-        if (pmh_rgb_table_generate(cie_x.data(), cie_y.data(), cie_z.data(), d65.data(), xyz_from_rgb.data(), z_nodes_.data(),
+        if (pmh_rgb_table_generate(cie_x.data(), cie_y.data(), cie_z.data(), d65.data(), nullptr, z_nodes_.data(),
                                    coeffs_.data(), 8) != 0)
             throw Error("Spectra: rgb table generation failed");
         if (std::FILE* f = std::fopen(path.c_str(), "wb")) {      // best effort cache
-            std::fwrite("PMRGBT1\0", 1, 8, f); std::fwrite(z_nodes_.data(), 4, 64, f); std::fwrite(coeffs_.data(), 4, n, f);
+            std::fwrite("PMRGBT2\0", 1, 8, f); std::fwrite(z_nodes_.data(), 4, 64, f); std::fwrite(coeffs_.data(), 4, n, f);
             std::fclose(f);
         }
     }

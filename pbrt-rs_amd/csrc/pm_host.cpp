@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <charconv>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -247,25 +248,35 @@ void pmh_rgb_spectrum_table(const float* c3, float scale, const float* illuminan
 float pmh_sigmoid_poly(const float* c3, float lambda) { return sigmoid_poly(c3, lambda); }
 
 // RGB -> sigmoid-polynomial coefficients.  The reference looks these up (trilinearly) in a 3x64^3 table file that
-// is missing from the snapshot (util/data.rs:1684-1702, .MISSING_LARGE_BLOBS); this solves the same optimisation
-// problem the table generator solves (Jakob & Hanika 2019: Gauss-Newton on the CIELAB residual of the spectrum
-// sigmoid(c0 l^2 + c1 l + c2) under the colour space's illuminant) directly for one RGB.  Not bit-identical to a
-// table lookup (no interpolation error here); see DESIGN.md.
+// is missing from the snapshot (util/data.rs:1684-1702, .MISSING_LARGE_BLOBS).  That file is the output of pbrt-v4's
+// table generator (rgb2spec_opt, Jakob & Hanika 2019), whose published algorithm is restated here step for step - not only
+// the optimisation problem but the numerical recipe, because the generator stops each Gauss-Newton solve as soon as the
+// squared CIELAB residual falls below 1e-6, so a table entry is "where the iteration stopped", not the optimum:
+//   * CIE 1931 observer and the illuminant at 5 nm (every fifth entry of the 1 nm tables), linearly interpolated at
+//     283 points over 360..830 nm, Simpson 3/8 weights;
+//   * for sRGB the generator's own 6-digit matrices (not the colour space's f32 ones);
+//   * central differences (eps 1e-4) for the Jacobian, at most 15 iterations, update first and test the residual of the
+//     point before the update, coefficients clamped to |c| <= 200.
+// Pinned by the reference's own vector (sampling/spectrum.rs:1031-1037): tests/test_oracle_golden.py.
 namespace {
-// Gauss-Newton solver of Jakob & Hanika's RGB -> sigmoid-polynomial fit (CIELAB residual under the colour space's
-// illuminant), in the normalised wavelength domain [0,1]; `co` is both the warm start and the result.
 struct RgbSolver {
-    static constexpr int N = 471;
+    static constexpr int NC = 95;                  // 5 nm samples
+    static constexpr int N = (NC - 1) * 3 + 1;     // 283 quadrature points
     std::vector<double> tbl, lam;
     double wp[3] = {0, 0, 0};
-    float xyz_from_rgb[9];
+    double xyz_from_rgb[9], rgb_from_xyz[9];
     bool ok = false;
+    // xyz_from_rgb9 == nullptr: sRGB with the generator's literal matrices
     RgbSolver(const float* cie_x, const float* cie_y, const float* cie_z, const float* illuminant471, const float* xyz_from_rgb9)
         : tbl(3 * N), lam(N) {
-        std::memcpy(xyz_from_rgb, xyz_from_rgb9, sizeof(xyz_from_rgb));
-        double rgb_from_xyz[9];
-        {   // 3x3 inverse
+        if (xyz_from_rgb9 == nullptr) {
+            const double to_xyz[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
+            const double to_rgb[9] = {3.240479, -1.537150, -0.498535, -0.969256, 1.875991, 0.041556, 0.055648, -0.204043, 1.057311};
+            std::memcpy(xyz_from_rgb, to_xyz, sizeof(to_xyz));
+            std::memcpy(rgb_from_xyz, to_rgb, sizeof(to_rgb));
+        } else {
             const float* m = xyz_from_rgb9;
+            for (int k = 0; k < 9; ++k) xyz_from_rgb[k] = m[k];
             double a = m[0], bb = m[1], c = m[2], d = m[3], e = m[4], f = m[5], gg = m[6], h = m[7], i = m[8];
             double det = a * (e * i - f * h) - bb * (d * i - f * gg) + c * (d * h - e * gg);
             if (det == 0) return;
@@ -274,41 +285,88 @@ struct RgbSolver {
                              (c * d - a * f) * id, (d * h - e * gg) * id, (bb * gg - a * h) * id, (a * e - bb * d) * id};
             std::memcpy(rgb_from_xyz, inv, sizeof(inv));
         }
-        // quadrature tables: tbl[c][i] = weight_i * I(l_i) * (rgb_from_xyz * xyz(l_i))[c], normalised so white -> (1,1,1)
-        double ynorm = 0;
-        for (int i = 0; i < N; ++i) {
-            double w = (i == 0 || i == N - 1) ? 0.5 : 1.0;   // trapezoid, 1 nm
-            double I = illuminant471[i];
-            double xyz[3] = {cie_x[i] * I * w, cie_y[i] * I * w, cie_z[i] * I * w};
-            ynorm += xyz[1];
-            for (int c = 0; c < 3; ++c) wp[c] += xyz[c];
-            for (int c = 0; c < 3; ++c) tbl[c * N + i] = rgb_from_xyz[c * 3 + 0] * xyz[0] + rgb_from_xyz[c * 3 + 1] * xyz[1] + rgb_from_xyz[c * 3 + 2] * xyz[2];
-            lam[i] = (double)i / (N - 1);
+        // The generator's tables are doubles parsed from the decimal literals of the CIE data (0.0002321, ...); the f32
+        // tables handed in here are those numbers rounded, so the shortest decimal that round-trips gives the literal back.
+        auto literal = [](float v) {
+            char buf[40];
+            auto r = std::to_chars(buf, buf + sizeof(buf) - 1, v);
+            *r.ptr = 0;
+            return std::strtod(buf, nullptr);
+        };
+        std::vector<double> t5(4 * NC);
+        for (int k = 0; k < NC; ++k) {
+            t5[k] = literal(cie_x[5 * k]); t5[NC + k] = literal(cie_y[5 * k]); t5[2 * NC + k] = literal(cie_z[5 * k]);
+            t5[3 * NC + k] = (double)illuminant471[5 * k];       // (computed, not a literal)
         }
+        auto interp = [&](int tab, double l) {          // linear interpolation of the 5 nm samples
+            double x = (l - 360.0) * ((NC - 1) / (830.0 - 360.0));
+            int off = (int)x;
+            if (off > NC - 2) off = NC - 2;
+            const double w = x - off;
+            return (1.0 - w) * t5[tab * NC + off] + w * t5[tab * NC + off + 1];
+        };
+        const double h = (830.0 - 360.0) / (N - 1);
+        for (int i = 0; i < N; ++i) {
+            const double l = 360.0 + i * h;
+            const double xyz[3] = {interp(0, l), interp(1, l), interp(2, l)};
+            const double I = interp(3, l);
+            double w = 3.0 / 8.0 * h;
+            if (i == 0 || i == N - 1) {}
+            else if ((i - 1) % 3 == 2) w *= 2.0;
+            else w *= 3.0;
+            lam[i] = (l - 360.0) / (830.0 - 360.0);
+            for (int c = 0; c < 3; ++c) {
+                double v = 0;
+                for (int k = 0; k < 3; ++k) v += rgb_from_xyz[c * 3 + k] * xyz[k] * I * w;
+                tbl[c * N + i] = v;
+                wp[c] += xyz[c] * I * w;
+            }
+        }
+        // the generator's illuminant table is pre-divided so that the white point has Y = 1; the table handed in here has
+        // another normalisation (the colour space's), so divide now
+        const double ynorm = wp[1];
+        if (!(ynorm > 0)) return;
         for (auto& v : tbl) v /= ynorm;
         for (int c = 0; c < 3; ++c) wp[c] /= ynorm;
         ok = true;
     }
     void lab(const double* rgbv, double* out) const {
         double xyz[3];
-        for (int k = 0; k < 3; ++k) xyz[k] = xyz_from_rgb[k * 3] * rgbv[0] + xyz_from_rgb[k * 3 + 1] * rgbv[1] + xyz_from_rgb[k * 3 + 2] * rgbv[2];
-        auto f = [](double t) { const double d = 6.0 / 29.0; return t > d * d * d ? std::cbrt(t) : t / (3 * d * d) + 4.0 / 29.0; };
+        for (int k = 0; k < 3; ++k) xyz[k] = rgbv[0] * xyz_from_rgb[k * 3] + rgbv[1] * xyz_from_rgb[k * 3 + 1] + rgbv[2] * xyz_from_rgb[k * 3 + 2];
+        auto f = [](double t) { const double d = 6.0 / 29.0; return t > d * d * d ? std::cbrt(t) : t / (d * d * 3.0) + 4.0 / 29.0; };
         double fx = f(xyz[0] / wp[0]), fy = f(xyz[1] / wp[1]), fz = f(xyz[2] / wp[2]);
-        out[0] = 116 * fy - 16; out[1] = 500 * (fx - fy); out[2] = 200 * (fy - fz);
+        out[0] = 116.0 * fy - 16.0; out[1] = 500.0 * (fx - fy); out[2] = 200.0 * (fy - fz);
     }
     void residual(const double* target, const double* co, double* res) const {
         double out[3] = {0, 0, 0};
         for (int i = 0; i < N; ++i) {
             double x = (co[0] * lam[i] + co[1]) * lam[i] + co[2];
-            double s = 0.5 + 0.5 * x / std::sqrt(1.0 + x * x);
+            double s = 0.5 * x / std::sqrt(1.0 + x * x) + 0.5;
             for (int c = 0; c < 3; ++c) out[c] += tbl[c * N + i] * s;
         }
         double l0[3], l1[3];
         lab(target, l0); lab(out, l1);
         for (int c = 0; c < 3; ++c) res[c] = l0[c] - l1[c];
     }
-    void solve(const double* target, double* co) const {
-        for (int it = 0; it < 30; ++it) {
+    // 3x3 solve by LU with partial pivoting
+    static bool solve3(double A[3][3], const double* b, double* x) {
+        int P[3] = {0, 1, 2};
+        for (int i = 0; i < 3; ++i) {
+            double mx = 0; int im = i;
+            for (int k = i; k < 3; ++k) if (std::fabs(A[k][i]) > mx) { mx = std::fabs(A[k][i]); im = k; }
+            if (mx < 1e-15) return false;
+            if (im != i) { std::swap(P[i], P[im]); for (int c = 0; c < 3; ++c) std::swap(A[i][c], A[im][c]); }
+            for (int j = i + 1; j < 3; ++j) {
+                A[j][i] /= A[i][i];
+                for (int k = i + 1; k < 3; ++k) A[j][k] -= A[j][i] * A[i][k];
+            }
+        }
+        for (int i = 0; i < 3; ++i) { x[i] = b[P[i]]; for (int k = 0; k < i; ++k) x[i] -= A[i][k] * x[k]; }
+        for (int i = 2; i >= 0; --i) { for (int k = i + 1; k < 3; ++k) x[i] -= A[i][k] * x[k]; x[i] /= A[i][i]; }
+        return true;
+    }
+    void solve(const double* target, double* co, int max_it = 15, double tol = 1e-6) const {
+        for (int it = 0; it < max_it; ++it) {
             double res[3]; residual(target, co, res);
             double J[3][3];
             for (int k = 0; k < 3; ++k) {
@@ -316,34 +374,24 @@ struct RgbSolver {
                 const double eps = 1e-4;
                 t[k] = co[k] - eps; residual(target, t, r0);
                 t[k] = co[k] + eps; residual(target, t, r1);
-                for (int j = 0; j < 3; ++j) J[j][k] = (r1[j] - r0[j]) / (2 * eps);
+                for (int j = 0; j < 3; ++j) J[j][k] = (r1[j] - r0[j]) * (1.0 / (2 * eps));
             }
-            // solve J x = res (Cramer)
-            double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
-                         J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
-            if (std::fabs(det) < 1e-30) break;
             double x[3];
-            for (int k = 0; k < 3; ++k) {
-                double M[3][3];
-                std::memcpy(M, J, sizeof(M));
-                for (int j = 0; j < 3; ++j) M[j][k] = res[j];
-                x[k] = (M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
-                        M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0])) / det;
-            }
+            if (!solve3(J, res, x)) break;
             double rr = 0;
             for (int k = 0; k < 3; ++k) { co[k] -= x[k]; rr += res[k] * res[k]; }
             double mx = std::fmax(std::fmax(std::fabs(co[0]), std::fabs(co[1])), std::fabs(co[2]));
             if (mx > 200) for (int k = 0; k < 3; ++k) co[k] *= 200 / mx;
-            if (rr < 1e-12) break;
+            if (rr < tol) break;
         }
     }
     // from the normalised wavelength domain to nanometres
     static void to_nm(const double* co, float* out_c3) {
         const double c0 = 360.0, c1 = 1.0 / (830.0 - 360.0);
         double A = co[0], B = co[1], C = co[2];
-        out_c3[0] = (float)(A * c1 * c1);
-        out_c3[1] = (float)(B * c1 - 2 * A * c0 * c1 * c1);
-        out_c3[2] = (float)(C - B * c0 * c1 + A * (c0 * c1) * (c0 * c1));
+        out_c3[0] = (float)(A * (c1 * c1));
+        out_c3[1] = (float)(B * c1 - 2 * A * c0 * (c1 * c1));
+        out_c3[2] = (float)(C - B * c0 * c1 + A * ((c0 * c1) * (c0 * c1)));
     }
 };
 }  // namespace
@@ -359,7 +407,7 @@ int pmh_rgb_to_coeffs(const float* rgb3, const float* cie_x, const float* cie_y,
     if (!sv.ok) return 1;
     const double target[3] = {rgb3[0], rgb3[1], rgb3[2]};
     double co[3] = {0, 0, 0};
-    sv.solve(target, co);
+    sv.solve(target, co, 60, 1e-12);        // no table, no warm start: iterate to convergence
     RgbSolver::to_nm(co, out_c3);
     return 0;
 }
@@ -380,7 +428,7 @@ int pmh_rgb_table_generate(const float* cie_x, const float* cie_y, const float* 
         const double x = (double)i / (R - 1), y = (double)j / (R - 1);
         const int start = R / 5;
         auto at = [&](int k, double* co) {
-            const double b = scale[k];
+            const double b = (double)z_nodes64[k];     // the generator keeps the nodes in f32
             double rgb[3];
             rgb[l] = b; rgb[(l + 1) % 3] = x * b; rgb[(l + 2) % 3] = y * b;
             sv.solve(rgb, co);

@@ -104,20 +104,21 @@ class Spectra:
     # tables) and looked up exactly as RGBToSpectrumTable::convert does; scripts/gen_rgbspectrum_table.py writes the same
     # table in the text format the reference loads.  rgb_mode="direct" solves each colour without the table instead.
     TABLE_PATH = os.path.join(os.path.dirname(_DATA), "rgbspectrum_srgb.bin")
-    _TABLE_MAGIC = b"PMRGBT1\0"
+    _TABLE_MAGIC = b"PMRGBT2\0"
 
     def rgb_table(self):
         if self._table is None:
             n = 3 * 64 ** 3 * 3
             path = self.TABLE_PATH
-            if os.path.exists(path) and os.path.getsize(path) == 8 + 4 * (64 + n):
+            if os.path.exists(path) and os.path.getsize(path) == 8 + 4 * (64 + n) and open(path, "rb").read(8) == self._TABLE_MAGIC:
                 raw = np.fromfile(path, np.float32, offset=8)
                 z, co = raw[:64].copy(), raw[64:].copy()
             else:
                 z, co = np.zeros(64, np.float32), np.zeros(n, np.float32)
                 threads = min(16, len(os.sched_getaffinity(0)))
+                # matrices = None: the 6-digit sRGB matrices the published table was generated with
                 if _capi.lib().pmh_rgb_table_generate(_p(self.cie_x), _p(self.cie_y), _p(self.cie_z), _p(self.d65),
-                                                      _p(self.xyz_from_rgb), _p(z), _p(co), threads) != 0:
+                                                      None, _p(z), _p(co), threads) != 0:
                     raise RuntimeError("rgb table generation failed")
                 try:
                     tmp = f"{path}.{os.getpid()}.tmp"

@@ -123,20 +123,24 @@ def _dense_at(ora, table, lam):
 
 
 def test_rgb_illuminant_spectrum(ora, spectra):
-    """RgbIlluminantSpectrum::new(&SRGB, (0.4,0.45,0.5)).at(lambda).  The reference looks the sigmoid coefficients up in
-    src/util/rgbspectrum_srgb.txt, a file missing from the snapshot; the product regenerates that table (same optimisation
-    problem, same grid, same trilinear lookup), so the match is to 5e-4 relative rather than to f32::EPSILON."""
+    """RgbIlluminantSpectrum::new(&SRGB, (0.4,0.45,0.5)).at(lambda), the reference's own vector
+    (sampling/spectrum.rs:1031-1037).  The reference looks the sigmoid coefficients up in src/util/rgbspectrum_srgb.txt, a
+    file missing from the snapshot; the product regenerates that table by the published recipe of its generator
+    (pm_host.cpp RgbSolver), and the vector is met by the reference's own criterion: assert_relative_eq!'s defaults,
+    |a-b| <= f32::EPSILON or <= f32::EPSILON * max(|a|,|b|)."""
     g = GOLD["rgb_illuminant_spectrum"]
     table, coeffs, scale = spectra.rgb_illuminant_table(g["rgb"])
     L = ora.lib()
     L.ora_sigmoid_poly.restype = C.c_float
     L.ora_sigmoid_poly.argtypes = [C.c_float] * 4
+    eps = float(np.finfo(np.float32).eps)
     for lam, e in g["cases"]:
-        dense = _dense_at(ora, table, lam)
-        assert abs(dense - e) <= 5e-4 * e, (lam, dense, e)
+        e = float(np.float32(e))
+        dense = float(_dense_at(ora, table, lam))
+        assert abs(dense - e) <= eps or abs(dense - e) <= eps * max(abs(dense), abs(e)), (lam, dense, e)
         direct = np.float32(scale) * np.float32(L.ora_sigmoid_poly(coeffs[0], coeffs[1], coeffs[2], lam)) * np.float32(
             _dense_at(ora, spectra.d65, lam))
-        assert abs(direct - e) <= 1e-3 * e, (lam, direct, e)
+        assert abs(float(direct) - e) <= 2 * eps * e, (lam, direct, e)
 
 
 def test_rgb_table_lookup_matches_oracle_and_direct_solve(ora, pm, spectra):
@@ -217,3 +221,29 @@ def test_sphere_setup1(ora, pm):
     assert hits["prim_id"][0] == 0
     p = d.astype(np.float64) * float(hits["t"][0])
     assert rel_eq(np.linalg.norm(p - centre.astype(np.float64)), g["radius"], g["max_relative"])
+
+
+def test_table_file_for_the_reference_parses_as_the_reference_parses_it(pm, spectra, tmp_path):
+    """scripts/gen_rgbspectrum_table.py writes the file the reference opens as ./src/util/rgbspectrum_srgb.txt
+    (util/data.rs:1684-1702): read_line -> usize == RESOLUTION (64); read_line -> serde_json Vec<f32> copied into
+    [f32; 64]; the rest of the reader -> serde_json Vec<f32> of 3*64^3*3 values (color_space.rs:194-197).  serde_json takes
+    no NaN / Infinity tokens and no trailing garbage, so neither may appear."""
+    import json
+    import subprocess
+    import sys
+    out = tmp_path / "rgbspectrum_srgb.txt"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(root, "scripts", "gen_rgbspectrum_table.py"), str(out)], check=True,
+                   stdout=subprocess.DEVNULL)
+    with open(out) as f:
+        res = int(f.readline().rstrip())          # str::trim_end + parse::<usize>
+        scale = json.loads(f.readline())
+        rest = f.read()
+    assert res == 64
+    assert isinstance(scale, list) and len(scale) == 64
+    assert "NaN" not in rest and "Infinity" not in rest
+    data = json.loads(rest)
+    assert isinstance(data, list) and len(data) == 3 * 64 ** 3 * 3 and all(isinstance(v, float) for v in data[:1000])
+    z, co = spectra.rgb_table()
+    assert np.array_equal(np.asarray(scale, np.float32), z)
+    assert np.array_equal(np.asarray(data, np.float32), co)
