@@ -4,6 +4,7 @@
 #include <atomic>
 #include <thread>
 
+#include "ref_host.h"
 #include "ref_integrator.h"
 #include "ref_render.h"
 #include "ref_scene.h"
@@ -437,6 +438,66 @@ uint32_t ora_pcg32_next(uint64_t* state_inc) {
 void ora_pcg32_new(uint64_t state, uint64_t stream, uint64_t* state_inc) {
     Pcg32 r = Pcg32::create(state, stream);
     state_inc[0] = r.state; state_inc[1] = r.inc;
+}
+
+// ---- the reference's scene-construction code (oracle/ref_host.h), one entry per constructor the product's host layer mirrors
+static host::T4 t4_from(const float* m16, const float* inv16) {
+    host::T4 t; std::memcpy(t.m.m, m16, 64); std::memcpy(t.inv.m, inv16, 64); return t;
+}
+int ora_host_look_at(const float* pos3, const float* look3, const float* up3, float* m16, float* inv16) {
+    host::T4 t;
+    if (!host::look_at(V3(pos3[0], pos3[1], pos3[2]), V3(look3[0], look3[1], look3[2]), V3(up3[0], up3[1], up3[2]), &t)) return 1;
+    std::memcpy(m16, t.m.m, 64); std::memcpy(inv16, t.inv.m, 64);
+    return 0;
+}
+int ora_host_perspective_camera(const float* wfc_m16, const float* wfc_inv16, float fov_deg, const float* screen_window4, int res_x,
+                                int res_y, float lens_radius, float focal_distance, OCamera* out, float* world_from_render16,
+                                float* render_from_world16) {
+    host::CameraOut co;
+    if (!host::perspective_camera(t4_from(wfc_m16, wfc_inv16), fov_deg, screen_window4, res_x, res_y, lens_radius, focal_distance, &co)) return 1;
+    *out = co.cam;
+    std::memcpy(world_from_render16, co.world_from_render.m.m, 64);
+    std::memcpy(render_from_world16, co.world_from_render.inv.m, 64);
+    return 0;
+}
+void ora_host_compose(const float* a_m, const float* a_inv, const float* b_m, const float* b_inv, float* m16, float* inv16) {
+    const host::T4 t = host::compose(t4_from(a_m, a_inv), t4_from(b_m, b_inv));
+    std::memcpy(m16, t.m.m, 64); std::memcpy(inv16, t.inv.m, 64);
+}
+void ora_host_translate(const float* d3, float* m16, float* inv16) {
+    const host::T4 t = host::translate(V3(d3[0], d3[1], d3[2]));
+    std::memcpy(m16, t.m.m, 64); std::memcpy(inv16, t.inv.m, 64);
+}
+int ora_host_frame_towards(const float* from3, const float* to3, float* m16, float* inv16) {
+    host::T4 t;
+    if (!host::frame_towards(V3(from3[0], from3[1], from3[2]), V3(to3[0], to3[1], to3[2]), &t)) return 1;
+    std::memcpy(m16, t.m.m, 64); std::memcpy(inv16, t.inv.m, 64);
+    return 0;
+}
+int ora_host_gaussian_filter_table(float rx, float ry, float sigma, float* vals, int cap, int* nx, int* ny) {
+    std::vector<float> v;
+    host::gaussian_filter_table(rx, ry, sigma, &v, nx, ny);
+    if (vals) { if ((int)v.size() > cap) return 1; std::memcpy(vals, v.data(), v.size() * sizeof(float)); }
+    return 0;
+}
+void ora_host_d65_table(const float* cie_y471, const float* d65_interleaved, int n, float* out471) { host::d65_dense(cie_y471, d65_interleaved, n, out471); }
+float ora_host_photometric(const float* cie_y471, const float* table471) { return host::photometric(cie_y471, table471); }
+float ora_host_blackbody_table(float temp, float* out471) { return host::blackbody_dense(temp, out471); }
+void ora_host_rgb_spectrum_table(const float* c3, float scale, const float* illum471_or_null, float* out471) {
+    host::rgb_spectrum_dense(c3, scale, illum471_or_null, out471);
+}
+int ora_host_srgb_matrices(const float* cie_x, const float* cie_y, const float* cie_z, const float* illum471, float* xyz_from_rgb9,
+                           float* rgb_from_xyz9) {
+    float a[3][3], b[3][3];
+    if (!host::srgb_matrices(cie_x, cie_y, cie_z, illum471, a, b)) return 1;
+    std::memcpy(xyz_from_rgb9, a, 36); std::memcpy(rgb_from_xyz9, b, 36);
+    return 0;
+}
+
+// BilinearPatchMesh::new / TriangleMesh::new transform their vertices with render_from_object * p (transform.rs:320-335)
+void ora_host_xf_points(const float* m16, const float* pts, int n, float* out) {
+    M4 m; std::memcpy(m.m, m16, 64);
+    for (int i = 0; i < n; ++i) { const V3 q = xf_point(m, V3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2])); out[3 * i] = q.x; out[3 * i + 1] = q.y; out[3 * i + 2] = q.z; }
 }
 
 }  // extern "C"

@@ -486,36 +486,51 @@ void pmh_rgb_table_lookup(const float* z_nodes64, const float* coeffs, const flo
     }
 }
 
-// RGBColorSpace::new for sRGB primaries (color/color_space.rs:40-89): xyz_from_rgb and rgb_from_xyz (f32)
+// RGBColorSpace::new for sRGB primaries (color/color_space.rs:40-89): xyz_from_rgb and rgb_from_xyz, in the reference's f32
+// arithmetic - SquareMatrix<3>::inverse with difference_of_products (square_matrix.rs:123-167), the matrix products with
+// mul_add accumulation (:316-332), matrix * tuple with plain += (:345-360).
+namespace {
+bool invert3(const float m[3][3], float r[3][3]) {
+    const float minor12 = dop(m[1][1], m[2][2], m[1][2], m[2][1]);
+    const float minor02 = dop(m[1][0], m[2][2], m[1][2], m[2][0]);
+    const float minor01 = dop(m[1][0], m[2][1], m[1][1], m[2][0]);
+    const float det = std::fmaf(m[0][2], minor01, dop(m[0][0], minor12, m[0][1], minor02));
+    if (det == 0.0f) return false;
+    const float k = 1.0f / det;
+    r[0][0] = k * dop(m[1][1], m[2][2], m[1][2], m[2][1]); r[1][0] = k * dop(m[1][2], m[2][0], m[1][0], m[2][2]);
+    r[2][0] = k * dop(m[1][0], m[2][1], m[1][1], m[2][0]); r[0][1] = k * dop(m[0][2], m[2][1], m[0][1], m[2][2]);
+    r[1][1] = k * dop(m[0][0], m[2][2], m[0][2], m[2][0]); r[2][1] = k * dop(m[0][1], m[2][0], m[0][0], m[2][1]);
+    r[0][2] = k * dop(m[0][1], m[1][2], m[0][2], m[1][1]); r[1][2] = k * dop(m[0][2], m[1][0], m[0][0], m[1][2]);
+    r[2][2] = k * dop(m[0][0], m[1][1], m[0][1], m[1][0]);
+    return true;
+}
+}  // namespace
 int pmh_srgb_matrices(const float* cie_x, const float* cie_y, const float* cie_z, const float* illuminant471,
                       float* xyz_from_rgb9, float* rgb_from_xyz9) {
     // W = illuminant.to_xyz() = (inner products) / CIE_Y_INTEGRAL
     float X = 0, Y = 0, Z = 0;
     for (int i = 0; i < 471; ++i) { X += illuminant471[i] * cie_x[i]; Y += illuminant471[i] * cie_y[i]; Z += illuminant471[i] * cie_z[i]; }
-    X /= 106.856895f; Y /= 106.856895f; Z /= 106.856895f;
+    const float W[3] = {X / 106.856895f, Y / 106.856895f, Z / 106.856895f};
     auto from_xyy = [](float x, float y, float* o) {   // XYZ::from_xyy with Y = 1
         if (y == 0.0f) { o[0] = o[1] = o[2] = 0.0f; return; }
         o[0] = x * 1.0f / y; o[1] = 1.0f; o[2] = (1.0f - x - y) * 1.0f / y;
     };
     float R[3], G[3], B[3];
     from_xyy(0.64f, 0.33f, R); from_xyy(0.3f, 0.6f, G); from_xyy(0.15f, 0.06f, B);
-    double m[9] = {R[0], G[0], B[0], R[1], G[1], B[1], R[2], G[2], B[2]};
-    double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
-    if (det == 0) return 1;
-    double id = 1.0 / det;
-    double inv[9] = {(m[4] * m[8] - m[5] * m[7]) * id, (m[2] * m[7] - m[1] * m[8]) * id, (m[1] * m[5] - m[2] * m[4]) * id,
-                     (m[5] * m[6] - m[3] * m[8]) * id, (m[0] * m[8] - m[2] * m[6]) * id, (m[2] * m[3] - m[0] * m[5]) * id,
-                     (m[3] * m[7] - m[4] * m[6]) * id, (m[1] * m[6] - m[0] * m[7]) * id, (m[0] * m[4] - m[1] * m[3]) * id};
-    double C[3] = {inv[0] * X + inv[1] * Y + inv[2] * Z, inv[3] * X + inv[4] * Y + inv[5] * Z, inv[6] * X + inv[7] * Y + inv[8] * Z};
-    double xr[9];
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) xr[r * 3 + c] = m[r * 3 + c] * C[c];
-    double d2 = xr[0] * (xr[4] * xr[8] - xr[5] * xr[7]) - xr[1] * (xr[3] * xr[8] - xr[5] * xr[6]) + xr[2] * (xr[3] * xr[7] - xr[4] * xr[6]);
-    if (d2 == 0) return 1;
-    double i2 = 1.0 / d2;
-    double rx[9] = {(xr[4] * xr[8] - xr[5] * xr[7]) * i2, (xr[2] * xr[7] - xr[1] * xr[8]) * i2, (xr[1] * xr[5] - xr[2] * xr[4]) * i2,
-                    (xr[5] * xr[6] - xr[3] * xr[8]) * i2, (xr[0] * xr[8] - xr[2] * xr[6]) * i2, (xr[2] * xr[3] - xr[0] * xr[5]) * i2,
-                    (xr[3] * xr[7] - xr[4] * xr[6]) * i2, (xr[1] * xr[6] - xr[0] * xr[7]) * i2, (xr[0] * xr[4] - xr[1] * xr[3]) * i2};
-    for (int k = 0; k < 9; ++k) { xyz_from_rgb9[k] = (float)xr[k]; rgb_from_xyz9[k] = (float)rx[k]; }
+    const float prim[3][3] = {{R[0], G[0], B[0]}, {R[1], G[1], B[1]}, {R[2], G[2], B[2]}};
+    float prim_inv[3][3];
+    if (!invert3(prim, prim_inv)) return 1;
+    float Cw[3] = {0.0f, 0.0f, 0.0f};
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Cw[r] += prim_inv[r][c] * W[c];
+    float xr[3][3], rx[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {            // prim * diagonal(Cw)
+            float acc = 0.0f;
+            for (int k = 0; k < 3; ++k) acc = std::fmaf(prim[r][k], k == c ? Cw[c] : 0.0f, acc);
+            xr[r][c] = acc;
+        }
+    if (!invert3(xr, rx)) return 1;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { xyz_from_rgb9[r * 3 + c] = xr[r][c]; rgb_from_xyz9[r * 3 + c] = rx[r][c]; }
     return 0;
 }
 
