@@ -51,7 +51,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR(ANY, MIXED) void trace_ke
     };
     pmd::trace_persistent<ANY, COUNT, MIXED>(nodes, prims, n, work, refill, stack + threadIdx.x, cand + threadIdx.x, TRACE_BLOCK,
                                       defer_list, work + PM_WORK_SLOTS, defer_cap, &tc, fetch, commit);
+#ifdef PM_DBG_UTIL
+    if (true) {
+#else
     if (COUNT) {
+#endif
         // wave-level reduction, one atomic per wave per counter
         unsigned long long nn = tc.nodes, pp = tc.prims, ee = tc.exact, ff = tc.fallback;
         for (int off = 32; off > 0; off >>= 1) {

@@ -435,6 +435,9 @@ struct SlowWriter {
 #ifndef PM_PEND_FLUSH
 #define PM_PEND_FLUSH 24
 #endif
+#ifndef PM_POOL_EXACT
+#define PM_POOL_EXACT 1        /* 0: every finished lane runs its own exact tests (one wave trip per queue slot) */
+#endif
 // The flat sweep meets candidates in table order, not front to back, so now and then a ray collects more than 4; a wave
 // makes as many exact-test trips as its busiest lane has candidates, so those rays are NOT given a deeper queue (measured:
 // depth 6 costs 14 %) but handed to the slow list.
@@ -494,6 +497,13 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
 #define PM_SURE (ANY ? sure_any : (tcull < ray.tmax))
     uint32_t qn = 0;
     constexpr bool DEFERL = PM_PEND_MAX > 0 && !ANY && !COUNT && !MIXED;
+    // Pooled exact tests (closest hit, triangle-only scenes): see the refill phase.  The finished lanes' candidates are
+    // dealt out over ALL lanes of the wave, one (ray, triangle) pair each.
+    constexpr bool POOL = PM_POOL_EXACT && !ANY && !MIXED && PM_LDS_STACK >= 6 && PM_CAND_MAX == 4;
+    __shared__ uint8_t pool_pairs[(POOL ? 4 : 1) * 64];        // per wave: (owner lane << 2 | candidate) of the pairs in flight
+    uint8_t* const my_pairs = pool_pairs + (POOL ? (threadIdx.x >> 6) * 64u : 0u);
+    uint2* const lds_w = lds - lane;                           // the wave's base of the strided per-lane arrays
+    uint32_t* const cand_w = cand - lane;
     uint32_t np = 0, ph = 0;                              // parked leaves: count, ring head
     uint32_t sph0 = 0xFFFFFFFFu, sph1 = 0xFFFFFFFFu;      // spheres that passed the pre-filter (deferred to sphere_fix)
     int sp = 0;
@@ -556,9 +566,74 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                     if (finished && np > 0u) drain_one();
                 }
             }
+            if (POOL) {
+                // The exact test is ~250 instructions and the loop below makes one wave trip per queue slot with only the lanes
+                // that still hold a candidate in that slot active (measured: these trips ran at ~15 % lane utilisation and took
+                // a fifth of the walk's instructions).  Here the (finished lane, candidate) pairs of the wave are numbered by a
+                // prefix sum and dealt out over all 64 lanes: a worker lane fetches the owner's ray with ds_bpermute, runs the
+                // test against the owner's tmax and leaves (t, u, v, id) in the owner's LDS slots - the lower-bound words of
+                // its queue and its (now unused) stack entries; the owner then applies its results in queue order with the
+                // sequential rule `t < tmax`, so ties resolve exactly as before.  The test's only use of t_max is that final
+                // comparison, so testing against the tmax of the start of the round changes nothing.
+                uint32_t vmask = 0u;
+                if (finished)
+                    for (uint32_t qj = 0; qj < PM_CAND_MAX; ++qj)
+                        if (qj < qn && !(__uint_as_float(cand[(PM_CAND_MAX + qj) * stride]) > tcull)) vmask |= 1u << qj;
+                const uint32_t myn = __popc(vmask);
+                const unsigned long long b0 = __ballot(myn & 1u), b1 = __ballot(myn & 2u), b2 = __ballot(myn & 4u);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const uint32_t pre = (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
+                const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+                for (uint32_t base = 0; base < total; base += 64u) {
+                    {   // owners publish the pairs of this window
+                        uint32_t m = vmask, k = 0;
+                        while (m) {
+                            const uint32_t j = __ffs(m) - 1u; m &= m - 1u;
+                            const uint32_t pidx = pre + k - base; ++k;
+                            if (pidx < 64u) my_pairs[pidx] = (uint8_t)((lane << 2) | j);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const bool work = lane < total - base;
+                    const uint32_t e = work ? (uint32_t)my_pairs[lane] : (lane << 2);
+                    const uint32_t owner = e >> 2, j = e & 3u;
+                    // every lane takes part in the shuffles (a disabled source lane would deliver nothing)
+                    const f3 wo = mk3(__shfl(ray.o.x, (int)owner), __shfl(ray.o.y, (int)owner), __shfl(ray.o.z, (int)owner));
+                    const f3 wd = mk3(__shfl(ray.d.x, (int)owner), __shfl(ray.d.y, (int)owner), __shfl(ray.d.z, (int)owner));
+                    const float wtmax = __shfl(tmax, (int)owner);
+                    if (work) {
+                        const uint4* r = prims + cand_w[j * stride + owner];
+                        const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
+                        const f3 v0 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
+                        const f3 v1 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
+                        const f3 v2 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
+                        if (COUNT) ctr->exact++;
+                        float t = INFINITY, u = 0.0f, v = 0.0f;
+                        if (!intersect_tri_exact(wo, wd, wtmax, v0, v1, v2, &t, &u, &v)) t = INFINITY;
+                        cand_w[(PM_CAND_MAX + j) * stride + owner] = __float_as_uint(t);
+                        lds_w[j * stride + owner] = make_uint2(__float_as_uint(u), __float_as_uint(v));
+                        reinterpret_cast<uint32_t*>(&lds_w[(4u + (j >> 1)) * stride + owner])[j & 1u] = r2.y;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                {   // owners apply their results in queue order
+                    uint32_t m = vmask;
+                    while (m) {
+                        const uint32_t j = __ffs(m) - 1u; m &= m - 1u;
+                        const float t = __uint_as_float(cand[(PM_CAND_MAX + j) * stride]);
+                        if (t < tmax) {
+                            const uint2 uv = lds[j * stride];
+                            tmax = t; found = true; hit.t = t; hit.u = __uint_as_float(uv.x); hit.v = __uint_as_float(uv.y);
+                            hit.prim_id = reinterpret_cast<const uint32_t*>(&lds[(4u + (j >> 1)) * stride])[j & 1u];
+                        }
+                    }
+                }
+            }
             if (finished) {
                 for (uint32_t qj = 0; qj < PM_CAND_MAX; ++qj) {
-                    if (qj >= qn || (ANY && found)) continue;
+                    if (POOL || qj >= qn || (ANY && found)) continue;
                     // any hit: last candidate first - a certain hit ends the walk, so it is the last one queued, and the round
                     // is over after one test (the candidates before it are mostly the triangle the shadow ray starts on)
                     const uint32_t qi = ANY ? qn - 1u - qj : qj;
@@ -626,6 +701,9 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
             }
             if (!__any(active) && !more && wnext >= wend) { if (MIXED) dw.pad(lane); break; }
         }
+#ifdef PM_DBG_UTIL
+        if (!COUNT) { const unsigned long long am = __ballot(active); if (active) { ctr->nodes++; if (lane == (uint32_t)__ffsll((long long)am) - 1u) ctr->prims++; } }
+#endif
         if (active) {
             // ---- one node step (the pop of an exhausted group is merged into it)
             bool ended = (ANY && (found || PM_SURE)) || ++steps > PM_WALK_GUARD;
@@ -785,6 +863,9 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
             const bool have = active && np > 0u;
             const unsigned long long hm = __ballot(have);
             if (hm != 0ull && ((uint32_t)__popcll(hm) >= PM_PEND_FLUSH || __any(active && np == PM_PEND_MAX))) {
+#ifdef PM_DBG_UTIL
+                if (have) { ctr->exact++; if (lane == (uint32_t)__ffsll((long long)hm) - 1u) ctr->fallback++; }
+#endif
                 if (have) drain_one();
             }
         }

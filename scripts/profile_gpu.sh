@@ -12,8 +12,17 @@ step stats-path
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_path -o path --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/stats_path.log 2>&1 || exit 1
 step stats-trace
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_trace -o trace --output-format csv -- python3 bench.py --workload trace --steps 5 --warmup 1 --no-cpu-baseline > $OUT/stats_trace.log 2>&1 || exit 1
-for W in path trace; do
-  if [ $W = path ]; then ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-secondary"; else ARGS="--workload trace --steps 1 --warmup 0 --no-cpu-baseline --no-secondary"; fi   # primary rays only: one kernel, one ray set
+step stats-c4
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_c4 -o c4 --output-format csv -- python3 bench.py --workload c4 --spp 8 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/stats_c4.log 2>&1 || exit 1
+step stats-c5
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_c5 -o c5 --output-format csv -- python3 bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/stats_c5.log 2>&1 || exit 1
+for W in ${PROFILE_WORKLOADS:-path trace c4 c5}; do
+  case $W in
+    path) ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-secondary";;
+    trace) ARGS="--workload trace --steps 1 --warmup 0 --no-cpu-baseline --no-secondary";;   # primary rays only: one kernel, one ray set
+    c4) ARGS="--workload c4 --spp 8 --steps 1 --warmup 0 --no-cpu-baseline";;
+    c5) ARGS="--workload c5 --steps 1 --warmup 0 --no-cpu-baseline";;
+  esac
   step pmc-fetch-$W
   timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum -d $OUT/pmc_fetch_$W -o f --output-format csv -- python3 bench.py $ARGS > $OUT/pmc_fetch_$W.log 2>&1 || exit 1
   step pmc-write-$W
