@@ -10,9 +10,10 @@ for lib in "" "$@"; do
   PBRT_MI355_LIB=${lib:+$R/$lib} timeout -k 10 200 python -u bench.py --steps 3 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('C2 %.1f Msamples/s (%.1f ms) kernel_ms %s' % (d['value']/1e6, d['ms_per_step'], {k: round(v,2) for k,v in d['config']['kernel_ms'].items()}))" >> $OUT 2>&1 || exit 1
+print('C2 %.1f Msamples/s (%.1f ms) kernel_ms %s' % (d['value']/1e6, d['ms_per_step'], {k: round(v['ms'],2) for k,v in d['roofline']['per_kernel'].items()}))" >> $OUT 2>&1 || exit 1
   PBRT_MI355_LIB=${lib:+$R/$lib} timeout -k 10 300 python -u bench.py --workload c4 --blobs 4096 --res 1920 --spp 16 --steps 2 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('C4-small %.1f Msamples/s  kernel_ms %s' % (d['value']/1e6, {k: round(v,1) for k,v in d['config']['kernel_ms'].items()}))" >> $OUT 2>&1 || exit 1
+print('C4-small %.1f Msamples/s  kernel_ms %s' % (d['value']/1e6, {k: round(v['ms'],1) for k,v in d['roofline']['per_kernel'].items()}))" >> $OUT 2>&1 || exit 1
 done
+cat $OUT
