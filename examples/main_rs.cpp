@@ -2,6 +2,7 @@
 //   main_rs <width> <height> <spp> <out.exr> [film.f64] [tables.bin]
 // Writes the image as OpenEXR (Image::write_exr) and, optionally, the raw f64 film (rgb_sum[3], weight_sum per pixel).
 #include <chrono>
+#include <string>
 #include <cstdio>
 #include <cstdlib>
 
@@ -20,7 +21,12 @@ int main(int argc, char** argv) {
         // main.rs:221-233: SimplePathIntegrator::new(5, true, true, camera, sampler, bvh, lights).render()
         pm::WavefrontIntegrator integrator(5, true, true, scene, spp);
         const auto t0 = std::chrono::steady_clock::now();
-        const PmRenderStats st = integrator.render();
+        // argv[7] = "waves": the reference's wave schedule (integrators/base.rs:85-127) with a progress line per wave; same film
+        const bool waves = argc > 7 && std::string(argv[7]) == "waves";
+        const PmRenderStats st = waves ? integrator.render_waves([&](int w0, int w1) {
+                                             std::fprintf(stderr, "wave [%d, %d) of %d spp done\n", w0, w1, spp);
+                                         })
+                                       : integrator.render();
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         integrator.write_exr(out);
         if (film_path) {

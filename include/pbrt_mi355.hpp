@@ -12,6 +12,7 @@
 //   WavefrontIntegrator       integrators/simple_path.rs:40-66, integrators/base.rs:32-45  ::new / render()
 // Errors: every failing C call throws pbrt_mi355::Error with the library's message (the reference panics).
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -301,6 +302,25 @@ public:
     int height() const { return sd_.film.pixel_bounds[3] - sd_.film.pixel_bounds[1]; }
     // Integrate::render(): the whole image, or params.window / params.s0..s1 of it
     PmRenderStats render() { agg_.check(pm_render(agg_.ctx(), &params)); PmRenderStats st{}; agg_.check(pm_get_render_stats(agg_.ctx(), &st)); return st; }
+    // the same in the reference's waves of sample indices (integrators/base.rs:85-127: [0,1) [1,2) [2,4) ... doubling up to 64);
+    // after each wave on_wave(wave_start, wave_end) may read a progressive image.  Final film bit-identical to render().
+    template <class F>
+    PmRenderStats render_waves(F on_wave) {
+        PmRenderStats st{};
+        const int spp = params.spp;
+        int wave_start = 0, wave_end = 1, next_wave_size = 1;
+        while (wave_start < spp) {
+            PmRenderParams p = params;
+            p.s0 = wave_start; p.s1 = wave_end;
+            agg_.check(pm_render(agg_.ctx(), &p));
+            on_wave(wave_start, wave_end);
+            wave_start = wave_end;
+            wave_end = std::min(spp, wave_end + next_wave_size);
+            next_wave_size = std::min(2 * next_wave_size, 64);
+        }
+        agg_.check(pm_get_render_stats(agg_.ctx(), &st));
+        return st;
+    }
     void clear() { agg_.check(pm_film_clear(agg_.ctx())); }
     std::vector<double> film() { std::vector<double> v(4 * (size_t)width() * height()); agg_.check(pm_film_read(agg_.ctx(), v.data())); return v; }
     std::vector<float> image() { std::vector<float> v(3 * (size_t)width() * height()); agg_.check(pm_film_image(agg_.ctx(), v.data())); return v; }

@@ -59,6 +59,30 @@ class WavefrontIntegrator:
         self.aggregate._check(self._lib.pm_render(self._h, C.byref(p)))
         return self.stats()
 
+    @staticmethod
+    def wave_schedule(spp):
+        """The sample-index waves of ImageTileIntegrate::image_tile_render (integrators/base.rs:85-127): [0,1), [1,2), [2,4),
+        [4,8) ... the wave size doubles up to 64, the last wave ends at spp."""
+        waves = []
+        wave_start, wave_end, next_wave_size = 0, 1, 1
+        while wave_start < spp:
+            waves.append((wave_start, wave_end))
+            wave_start = wave_end
+            wave_end = min(spp, wave_end + next_wave_size)
+            next_wave_size = min(2 * next_wave_size, 64)
+        return waves
+
+    def render_waves(self, window=None, on_wave=None):
+        """Integrate::render() in the reference's waves.  After each wave the film holds every sample index below wave_end,
+        so `on_wave(wave_start, wave_end, self)` may read a progressive image (`image()`, `film()`, `write_exr`).  The final
+        film is bit-identical to one `render()` call: samples are accumulated in sample-index order either way."""
+        stats = None
+        for w0, w1 in self.wave_schedule(self.params.spp):
+            stats = self.render(window, (w0, w1))
+            if on_wave is not None:
+                on_wave(w0, w1, self)
+        return stats
+
     def clear(self):
         self.aggregate._check(self._lib.pm_film_clear(self._h))
 

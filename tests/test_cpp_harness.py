@@ -35,3 +35,10 @@ def test_cpp_and_python_hosts_render_the_same_film(pm, tmp_path):
     np.testing.assert_allclose(cpp, py, rtol=1e-6, atol=1e-9)
     from test_host_logic import _read_exr
     np.testing.assert_allclose(_read_exr(exr_path), integ.image(), rtol=1e-5, atol=1e-7)
+    # the reference's wave schedule through the C++ mirror: progress per wave, the same film bit for bit
+    film2 = tmp_path / "film_waves.f64"
+    r = subprocess.run([EXE, str(w), str(h), str(spp), str(tmp_path / "img2.exr"), str(film2), "pbrt-rs_amd/data/cie_tables.bin", "waves"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert [l for l in r.stderr.splitlines() if l.startswith("wave [")] == [f"wave [{a}, {b}) of {spp} spp done" for a, b in ((0, 1), (1, 2), (2, 4), (4, 8))]
+    assert np.array_equal(np.fromfile(film2, np.float64).view(np.uint64), np.fromfile(film_path, np.float64).view(np.uint64))

@@ -143,6 +143,25 @@ def test_gaussian_filter_table(pm):
     assert np.allclose(v, v.T, rtol=1e-6)
 
 
+def test_wave_schedule(pm):
+    """the sample-index waves of ImageTileIntegrate::image_tile_render (integrators/base.rs:85-127), restated here literally"""
+    def reference(spp):
+        out, wave_start, wave_end, next_wave_size = [], 0, 1, 1
+        while wave_start < spp:
+            out.append((wave_start, wave_end))
+            wave_start = wave_end
+            wave_end = min(spp, wave_end + next_wave_size)
+            next_wave_size = min(2 * next_wave_size, 64)
+        return out
+    ws = pm.WavefrontIntegrator.wave_schedule
+    assert ws(256) == [(0, 1), (1, 2), (2, 4), (4, 8), (8, 16), (16, 32), (32, 64), (64, 128), (128, 192), (192, 256)]
+    for spp in (1, 2, 3, 7, 64, 65, 200, 1000):
+        w = ws(spp)
+        assert w == reference(spp)
+        assert w[0][0] == 0 and w[-1][1] == spp and all(a[1] == b[0] for a, b in zip(w, w[1:]))
+        assert max(b - a for a, b in w) <= 64
+
+
 def test_shard_maths(pm):
     d = pm.distributed
     for spp in (1, 7, 64, 65):

@@ -182,6 +182,27 @@ def test_window_and_sample_split_are_bit_identical(pm, ora):
     np.testing.assert_allclose(integ.film(), whole, rtol=1e-14, atol=0)
 
 
+def test_wave_schedule_readback(pm):
+    """integrators/base.rs:85-127: rendering in the reference's waves gives the same film bit for bit, and after every wave
+    the film is the finished image of the sample indices rendered so far (weight sums grow wave by wave)"""
+    res, spp = (40, 24), 21
+    sd = pm.scenes.main_rs_scene(res)
+    integ = pm.WavefrontIntegrator(5, True, True, sd, spp)
+    integ.render()
+    whole = integ.film().copy()
+    integ.clear()
+    seen = []
+
+    def on_wave(w0, w1, it):
+        f = it.film()
+        assert np.isfinite(it.image()).all()
+        seen.append((w0, w1, float(f[..., 3].sum())))
+    integ.render_waves(on_wave=on_wave)
+    assert [(a, b) for a, b, _ in seen] == [(0, 1), (1, 2), (2, 4), (4, 8), (8, 16), (16, 21)]
+    assert all(x[2] < y[2] for x, y in zip(seen, seen[1:]))
+    assert np.array_equal(integ.film().view(np.uint64), whole.view(np.uint64))
+
+
 def test_film_exchange_through_device_pointers(pm):
     """the multi-GPU merge path of bench.py: film read into / added from buffers that live in HBM (torch tensors)"""
     import torch
