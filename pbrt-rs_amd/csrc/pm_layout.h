@@ -73,4 +73,11 @@ struct PmFlatScene { const PmFlatTri* tris; const uint32_t* units; uint32_t n_sp
                              // (profiles/r02/ab_deferl.log): 8 entries = 16 KB 57 ms, 6 = 54 ms, 5 = 56 ms, 4 = 59 ms on the
                              // C4-small closest-hit launches; 12 entries held the walk to 4 waves per SIMD)
 #endif
-#define PM_SPILL_STACK (48 - PM_LDS_STACK)    // per-lane overflow entries (private memory)
+#ifndef PM_STACK_TOTAL
+#define PM_STACK_TOTAL 48    // traversal stack entries per ray; one entry per tree level at most (a group of hit siblings still to
+                             // visit).  A wide level is at least one binary level, so the device LBVH (63-bit Morton codes: binary
+                             // depth <= 63 + log2 n) and any SAH tree of a sane scene stay far below it.  Beyond: the group is
+                             // dropped and the call returns PM_ERR_STACK_OVERFLOW (tests/test_stack_overflow_gpu.py provokes it
+                             // with the 3-entry build `make smallstack`).
+#endif
+#define PM_SPILL_STACK (PM_STACK_TOTAL - PM_LDS_STACK)    // per-lane overflow entries (private memory)
