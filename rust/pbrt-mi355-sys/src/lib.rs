@@ -252,3 +252,22 @@ extern "C" {
     pub fn pm_debug_sample(ctx: *mut pm_ctx, params: *const PmRenderParams, px: i32, py: i32, sample_index: i32, out13: *mut f32) -> i32;
     pub fn pm_debug_uniforms(ctx: *mut pm_ctx, px: i32, py: i32, seed: u32, sample_index: u64, dimension: u64, n: i32, out: *mut f32) -> i32;
 }
+
+// Layout guards: the sizes the C header asserts (include/pbrt_mi355.h, PM_STATIC_ASSERT block).  A field added on one side
+// only fails the build here as it fails tests/test_rust_bindings.py there.
+const _: () = {
+    use core::mem::size_of;
+    assert!(size_of::<PmRay>() == 32);
+    assert!(size_of::<PmHit>() == 16);
+    assert!(size_of::<PmSphere>() == 152);
+    assert!(size_of::<PmAccelInfo>() == 80);
+    assert!(size_of::<PmCounters>() == 48);
+    assert!(size_of::<PmSpectrum>() == 32);
+    assert!(size_of::<PmMaterial>() == 104);
+    assert!(size_of::<PmLight>() == 88);
+    assert!(size_of::<PmMedium>() == 48);
+    assert!(size_of::<PmCamera>() == 136);
+    assert!(size_of::<PmFilm>() == 112);
+    assert!(size_of::<PmRenderParams>() == 48);
+    assert!(size_of::<PmRenderStats>() == 184);
+};
