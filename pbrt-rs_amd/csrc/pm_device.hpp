@@ -431,9 +431,15 @@ struct SlowWriter {
 #define PM_PEND_MAX 4          /* 0 disables; power of two */
 #endif
 // words of the per-lane candidate array a kernel instance needs (the ring exists only where the walk parks leaves)
-#define PM_CAND_WORDS(ANY, COUNT, MIXED) (2 * PM_CAND_MAX + ((ANY) || (COUNT) || (MIXED) ? 0 : PM_PEND_MAX))
+#ifndef PM_PEND_ANY
+#define PM_PEND_ANY 1          /* park leaves in the any-hit walk too */
+#endif
+#define PM_CAND_WORDS(ANY, COUNT, MIXED) (2 * PM_CAND_MAX + (((ANY) && !PM_PEND_ANY) || (COUNT) || (MIXED) ? 0 : PM_PEND_MAX))
 #ifndef PM_PEND_FLUSH
 #define PM_PEND_FLUSH 24
+#endif
+#ifndef PM_PEND_FLUSH_ANY
+#define PM_PEND_FLUSH_ANY 16     /* any hit: an occluder ends the walk, so learning of it early is worth smaller trips (12 / 16 / 24 / 32 measured) */
 #endif
 #ifndef PM_POOL_EXACT
 #define PM_POOL_EXACT 1        /* 0: every finished lane runs its own exact tests (one wave trip per queue slot) */
@@ -496,7 +502,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
     bool sure_any = false;
 #define PM_SURE (ANY ? sure_any : (tcull < ray.tmax))
     uint32_t qn = 0;
-    constexpr bool DEFERL = PM_PEND_MAX > 0 && !ANY && !COUNT && !MIXED;
+    constexpr bool DEFERL = PM_PEND_MAX > 0 && (PM_PEND_ANY || !ANY) && !COUNT && !MIXED;
     // Pooled exact tests (closest hit, triangle-only scenes): see the refill phase.  The finished lanes' candidates are
     // dealt out over ALL lanes of the wave, one (ray, triangle) pair each.
     constexpr bool POOL = PM_POOL_EXACT && !ANY && !MIXED && PM_LDS_STACK >= 6 && PM_CAND_MAX == 4;
@@ -531,7 +537,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
         float th, tl;
         const int cls = tri_prefilter(ray.o, ray.d, R, D, p00, p10, p01, tcull, &th, &tl);
         if (cls != 0) {
-            if (cls == 2) tcull = th;
+            if (cls == 2) { if (ANY) sure_any = true; else tcull = th; }
             if (qn < PM_CAND_MAX) {
                 cand[qn * stride] = unit; cand[(PM_CAND_MAX + qn) * stride] = __float_as_uint(tl);
                 ++qn;
@@ -562,8 +568,10 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
             bool defer = false;
             if (DEFERL) {        // lanes whose walk has ended: what is still parked goes through the pre-filter now, together
                 for (int k = 0; k < PM_PEND_MAX; ++k) {
-                    if (!__any(finished && np > 0u)) break;
-                    if (finished && np > 0u) drain_one();
+                    // (any hit: a ray that already has its occluder needs none of what it parked)
+                    const bool todo = finished && np > 0u && !(ANY && (found || sure_any));
+                    if (!__any(todo)) break;
+                    if (todo) drain_one();
                 }
             }
             if (POOL) {
@@ -862,7 +870,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
         if (DEFERL) {       // one pre-filter trip for the walking lanes, when enough of them have a leaf parked
             const bool have = active && np > 0u;
             const unsigned long long hm = __ballot(have);
-            if (hm != 0ull && ((uint32_t)__popcll(hm) >= PM_PEND_FLUSH || __any(active && np == PM_PEND_MAX))) {
+            if (hm != 0ull && ((uint32_t)__popcll(hm) >= (ANY ? PM_PEND_FLUSH_ANY : PM_PEND_FLUSH) || __any(active && np == PM_PEND_MAX))) {
 #ifdef PM_DBG_UTIL
                 if (have) { ctr->exact++; if (lane == (uint32_t)__ffsll((long long)hm) - 1u) ctr->fallback++; }
 #endif
