@@ -446,6 +446,9 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup, work
                    "shadow_prims_per_ray": st_c["shadow_prims"] / max(1, st_c["shadow_rays"]),
                    "exact_tests_per_ray": st_c["exact_tests"] / max(1, st_c["closest_rays"] + st_c["shadow_rays"]),
                    "fallback_walks": st_c["fallback_walks"],
+                   "dead_end_rays": "not traced: a ray towards a path's last vertex whose emission cannot reach the film (no infinite / "
+                                    "area light, or a non-specular bounce with light sampling on) - the reference traces it and drops "
+                                    "the result; the film is bit-identical (DESIGN.md 5.1)",
                    "queue_entries_per_bounce": {"closest": [int(x) for x in q_closest], "shadow": [int(x) for x in q_shadow],
                                                 "occupancy": [float(x) / max(1.0, float(q_closest[0])) for x in q_closest]},
                    "generator": "numpy PCG64 (default_rng); see scenes.py"},

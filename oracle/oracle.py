@@ -186,7 +186,12 @@ class Renderer:
     def render(self, params, nthreads=8):
         ctr = np.zeros(4, np.uint64)
         self._l.ora_renderer_render(self._h, C.addressof(params), nthreads, ctr.ctypes.data)
-        return {"samples": int(ctr[0]), "closest_rays": int(ctr[1]), "shadow_rays": int(ctr[2]), "bounces": int(ctr[3])}
+        self._l.ora_renderer_dead_final_rays.restype = C.c_uint64
+        self._l.ora_renderer_dead_final_rays.argtypes = [C.c_void_p]
+        dead = int(self._l.ora_renderer_dead_final_rays(self._h))
+        # useful_closest_rays: what the device traces (it elides rays towards a last vertex that cannot add to the film)
+        return {"samples": int(ctr[0]), "closest_rays": int(ctr[1]), "shadow_rays": int(ctr[2]), "bounces": int(ctr[3]),
+                "dead_final_rays": dead, "useful_closest_rays": int(ctr[1]) - dead}
 
     def clear(self):
         self._l.ora_renderer_clear(self._h)

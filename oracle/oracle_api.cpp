@@ -279,6 +279,7 @@ struct OraRenderer {
     Renderer r;
     std::vector<std::vector<float>> tables;   // owned copies of every table the description points to
     const float* own(const float* p, size_t n) { tables.emplace_back(p, p + n); return tables.back().data(); }
+    uint64_t last_dead_final_rays = 0;
 };
 OraRenderer* ora_renderer_create(OraScene* s, const OMaterial* mats, uint32_t n_mats, const uint32_t* prim_mat, uint32_t n_prims,
                                  const OLight* lights, uint32_t n_lights, const OCamera* cam, const OFilm* film) {
@@ -312,7 +313,9 @@ void ora_renderer_set_medium(OraRenderer* o, const float* sigma_a471, const floa
 void ora_renderer_render(OraRenderer* o, const ORender* rp, int nthreads, uint64_t* counters4) {
     RenderCounters rc = o->r.render(*rp, nthreads);
     if (counters4) { counters4[0] = rc.samples; counters4[1] = rc.closest_rays; counters4[2] = rc.shadow_rays; counters4[3] = rc.bounces; }
+    o->last_dead_final_rays = rc.dead_final_rays;
 }
+uint64_t ora_renderer_dead_final_rays(OraRenderer* o) { return o->last_dead_final_rays; }   // of the last ora_renderer_render
 void ora_renderer_clear(OraRenderer* o) { std::fill(o->r.pixels.begin(), o->r.pixels.end(), 0.0); }
 void ora_renderer_film(OraRenderer* o, double* rgbw) { std::memcpy(rgbw, o->r.pixels.data(), o->r.pixels.size() * sizeof(double)); }
 void ora_renderer_image(OraRenderer* o, float* rgb) { o->r.get_image(rgb); }

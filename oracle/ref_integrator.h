@@ -545,7 +545,11 @@ struct BSDF {   // reflection/base.rs:88-184, core/frame.rs:57-80
 };
 
 // ---- the renderer ---------------------------------------------------------------------------------------
-struct RenderCounters { uint64_t closest_rays = 0, shadow_rays = 0, samples = 0, bounces = 0; };
+// dead_final_rays: closest-hit rays of SimplePath / VolPath traced towards the LAST vertex of a path whose result cannot reach
+// the film - that vertex only adds emission (simple_path.rs:156-158,124-132), which needs (specular_bounce || !sample_lights)
+// and an infinite or area light in the scene.  The reference traces them; the device elides them (same film), so its ray
+// counts are compared with closest_rays - dead_final_rays.
+struct RenderCounters { uint64_t closest_rays = 0, shadow_rays = 0, samples = 0, bounces = 0, dead_final_rays = 0; };
 
 struct Renderer {
     const Scene* scene;
@@ -722,9 +726,12 @@ struct Renderer {
         bool specular_bounce = true;
         int depth = 0;
         const bool use_medium = vol && have_medium;
+        bool terminal_emission = !infinite_lights.empty();
+        for (const auto& l : lights) if (l.type == LIGHT_DIFFUSE_AREA) terminal_emission = true;
         while (!spec_all_zero(beta)) {
             Hit h;
             rc->closest_rays++;
+            if (depth == rp.max_depth && !((specular_bounce || !rp.sample_lights) && terminal_emission)) rc->dead_final_rays++;
             bool hit = scene->intersect(ro, rd, std::numeric_limits<float>::infinity(), &h);
             if (use_medium) {
                 float t0, t1;
@@ -938,7 +945,7 @@ struct Renderer {
         if (nthreads <= 1) work(0);
         else { std::vector<std::thread> th; for (int t = 0; t < nthreads; ++t) th.emplace_back(work, t); for (auto& t : th) t.join(); }
         RenderCounters tot;
-        for (auto& r : rcs) { tot.closest_rays += r.closest_rays; tot.shadow_rays += r.shadow_rays; tot.samples += r.samples; tot.bounces += r.bounces; }
+        for (auto& r : rcs) { tot.closest_rays += r.closest_rays; tot.shadow_rays += r.shadow_rays; tot.samples += r.samples; tot.bounces += r.bounces; tot.dead_final_rays += r.dead_final_rays; }
         return tot;
     }
 

@@ -417,6 +417,15 @@ __device__ __forceinline__ bool sample_light(const RenderConst& rc, const SceneA
     return true;
 }
 
+// A continuation ray towards the LAST vertex of a path (depth == max_depth once it is traced) can only pick up emission there:
+// the environment's or an area light's radiance, and only if (specular_bounce || !sample_lights) (simple_path.rs:124-132,
+// 156-158; the loop breaks before anything else happens at that vertex).  When that is impossible the reference still traces
+// the ray and discards the result; here it is not queued at all - same film, one closest-hit launch less per frame for a
+// scene without such lights (C2), and only the specular paths in the last launch otherwise.
+__device__ __forceinline__ bool dead_end(const RenderConst& rc, int depth_after, bool specular) {
+    return depth_after == rc.max_depth && !(rc.terminal_emission && (specular || !rc.sample_lights));
+}
+
 // EXT: the scene holds area lights and / or the integrator is PM_INTEGRATOR_VOL_PATH with a medium set.  That code (emission on
 // a hit, shape sampling, the medium event as a third outcome beside "surface" and "escaped") is compiled only into the EXT
 // variant: it costs registers, and the plain variant is the hot kernel of the C2 / C4 frames.
@@ -515,7 +524,8 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                             f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
                             float ppdf;
                             const f3 wi = sample_henyey_greenstein(wo, rc.med_g, u2, &ppdf);
-                            if (ppdf != 0.0f && !(beta[0] == 0.0f && beta[1] == 0.0f && beta[2] == 0.0f && beta[3] == 0.0f)) {
+                            if (ppdf != 0.0f && !(beta[0] == 0.0f && beta[1] == 0.0f && beta[2] == 0.0f && beta[3] == 0.0f) &&
+                                !dead_end(rc, depth, false)) {
                                 c_o = p; c_d = wi; c_misc = (uint32_t)depth;      // specular_bounce = false
                                 cont = true;
                             }
@@ -632,7 +642,7 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                 specular = false;
                 wi_next = wi; ok = true;
             }
-            if (ok && !(beta[0] == 0.0f && beta[1] == 0.0f && beta[2] == 0.0f && beta[3] == 0.0f)) {
+            if (ok && !(beta[0] == 0.0f && beta[1] == 0.0f && beta[2] == 0.0f && beta[3] == 0.0f) && !dead_end(rc, depth, specular)) {
                 c_o = offset_ray_origin(si, wi_next); c_d = wi_next;
                 c_misc = (uint32_t)depth | (specular ? 1u << 8 : 0u);
                 cont = true;
@@ -1159,6 +1169,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     rc.integrator = p->integrator; rc.max_depth = p->max_depth; rc.sample_lights = p->sample_lights; rc.sample_bsdf = p->sample_bsdf;
     rc.seed = p->seed; rc.n_lights = (int)r->lights.size(); rc.n_infinite = r->n_inf;
     rc.medium_on = (p->integrator == PM_INTEGRATOR_VOL_PATH && r->have_medium) ? 1 : 0;
+    rc.terminal_emission = (r->n_inf > 0 || r->have_area_lights) ? 1 : 0;
     rc.med_sigma_a = r->med_off_a; rc.med_sigma_s = r->med_off_s; rc.med_g = r->medium.g;
     std::memcpy(rc.med_bounds, r->medium.bounds, sizeof(rc.med_bounds));
     const bool shade_ext = rc.medium_on || r->have_area_lights || r->have_textures;

@@ -226,6 +226,7 @@ struct RenderConst {
     int integrator, max_depth, sample_lights, sample_bsdf;
     uint32_t seed;
     int n_lights, n_infinite;
+    int terminal_emission;    // the scene has an infinite or an area light: a path's last vertex can add emission (see dead_end)
     float scene_radius;
     // homogeneous medium of PM_INTEGRATOR_VOL_PATH (media/medium.rs:41-97): 471-entry tables in the pool, HG g, bounds
     int medium_on, med_sigma_a, med_sigma_s;

@@ -46,7 +46,7 @@ def test_c5_faithful_mode_statistics(pm, ora):
     oc = oren.render(p, 8)
     gi, oi = integ.image(), oren.image()
     assert np.isfinite(gi).all() and gi.mean() > 0
-    assert abs(st["closest_rays"] - oc["closest_rays"]) <= 5e-3 * oc["closest_rays"]
+    assert abs(st["closest_rays"] - oc["useful_closest_rays"]) <= 5e-3 * oc["closest_rays"]
     assert abs(gi.mean() - oi.mean()) <= 5e-3 * abs(oi.mean())
     assert helpers.rel_rmse(gi, oi) <= 5e-2
 

@@ -56,7 +56,7 @@ def test_main_rs_scene_image_and_samples(pm, ora):
     oc = oren.render(params, 8)
     assert st["samples"] == oc["samples"] == res[0] * res[1] * spp
     # ray counts agree up to the rare flipped paths
-    assert abs(st["closest_rays"] - oc["closest_rays"]) <= 2e-3 * oc["closest_rays"]
+    assert abs(st["closest_rays"] - oc["useful_closest_rays"]) <= 2e-3 * oc["closest_rays"]
     assert abs(st["shadow_rays"] - oc["shadow_rays"]) <= 2e-3 * oc["shadow_rays"]
     gi, oi = integ.image(), oren.image()
     assert np.isfinite(gi).all()
@@ -122,7 +122,7 @@ def test_c4_shaped_scene_small(pm, ora):
     assert frac >= 0.99, f"only {frac:.3f} of the samples agree"
     st = integ.render()
     oc = oren.render(params, 8)
-    assert abs(st["closest_rays"] - oc["closest_rays"]) <= 3e-3 * oc["closest_rays"]
+    assert abs(st["closest_rays"] - oc["useful_closest_rays"]) <= 3e-3 * oc["closest_rays"]
     gi, oi = integ.image(), oren.image()
     assert abs(gi.mean() - oi.mean()) <= 3e-3 * abs(oi.mean())
     assert helpers.rel_rmse(gi, oi) <= 3e-2
@@ -143,7 +143,7 @@ def test_random_walk_integrator(pm, ora):
     st = integ.render()
     oc = oren.render(params, 8)
     assert st["shadow_rays"] == oc["shadow_rays"] == 0
-    assert abs(st["closest_rays"] - oc["closest_rays"]) <= 2e-3 * oc["closest_rays"]
+    assert abs(st["closest_rays"] - oc["useful_closest_rays"]) <= 2e-3 * oc["closest_rays"]
     gi, oi = integ.image(), oren.image()
     assert np.isfinite(gi).all() and gi.mean() > 0
     assert abs(gi.mean() - oi.mean()) <= 5e-3 * abs(oi.mean())
