@@ -48,12 +48,11 @@ using namespace pmd;
 // (added to by unoccluded shadow rays and escaped rays), and what accumulate_kernel needs at the end.
 #define PM_DEAD 0xFFFFFFFFu
 #define PM_CNT_STRIDE 64
-#define PM_PATH_BYTES (2 * (16 + 16 + 16 + 16 + 8) + 16 + 48 + 16 + 16 + 16 + 4)       /* device bytes per path of a pass */
+#define PM_PATH_BYTES (2 * (16 + 16 + 16 + 8) + 16 + 48 + 16 + 16 + 16 + 4)       /* device bytes per path of a pass */
 struct PathArrays {
     float4* ro[2];      // xyz ray origin, w = slot (uint bits)
     float4* rd[2];      // xyz ray direction, w = depth | specular_bounce << 8 (uint bits); PM_DEAD = padded slot of a ragged window
     float4* beta[2];
-    float4* lambda[2];
     uint2* rng[2];      // PCG32 state; the increment follows from the slot's sample index (rng_inc_of)
     float4* hit;        // per entry of the current queue: closest-hit writes, shade reads
     float4 *sh_o, *sh_d, *sh_L;     // per entry of the SHADOW queue: origin + t_max, direction + slot, contribution if unoccluded
@@ -123,7 +122,6 @@ __global__ __launch_bounds__(RB) void raygen_kernel(RenderConst rc, SceneArrays 
     pa.ro[0][slot] = with_w(o, slot);
     pa.rd[0][slot] = with_w(d, 0u | (1u << 8));                    // depth 0, specular_bounce = true
     pa.beta[0][slot] = make_float4(1.f, 1.f, 1.f, 1.f);
-    pa.lambda[0][slot] = make_float4(lam[0], lam[1], lam[2], lam[3]);
     pa.rng[0][slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
     pa.L[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     pa.lambda_s[slot] = make_float4(lam[0], lam[1], lam[2], lam[3]);
@@ -454,7 +452,7 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
         const float4 hv = nt_load(pa.hit + i);
         const uint32_t prim_id = __float_as_uint(hv.x);
         const float4 b4 = nt_load(pa.beta[g] + i);
-        l4 = nt_load(pa.lambda[g] + i);
+        l4 = pa.lambda_s[slot];         // by slot: the wavelengths never change along a path, so they are not carried in the queue
         beta[0] = b4.x; beta[1] = b4.y; beta[2] = b4.z; beta[3] = b4.w;
         const float lam[4] = {l4.x, l4.y, l4.z, l4.w};
         int depth = (int)(mw & 0xFFu);
@@ -657,7 +655,6 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
         nt_store(pa.ro[h] + oi, with_w(c_o, slot));
         nt_store(pa.rd[h] + oi, with_w(c_d, c_misc));
         nt_store(pa.beta[h] + oi, make_float4(beta[0], beta[1], beta[2], beta[3]));
-        nt_store(pa.lambda[h] + oi, l4);
         nt_store(pa.rng[h] + oi, make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32)));
     }
     if (want_shadow) {
@@ -690,7 +687,7 @@ __global__ __launch_bounds__(RB) void shade_rw_kernel(RenderConst rc, SceneArray
         slot = __float_as_uint(ro4.w);
         const float4 hv = pa.hit[i];
         const uint32_t prim_id = __float_as_uint(hv.x);
-        l4 = pa.lambda[g][i];
+        l4 = pa.lambda_s[slot];
         const float lam[4] = {l4.x, l4.y, l4.z, l4.w};
         const int depth = (int)(mw & 0xFFu);
         float Lr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -738,7 +735,6 @@ __global__ __launch_bounds__(RB) void shade_rw_kernel(RenderConst rc, SceneArray
         const uint32_t h = g ^ 1u;
         pa.ro[h][oi] = with_w(c_o, slot);
         pa.rd[h][oi] = with_w(c_d, c_misc);
-        pa.lambda[h][oi] = l4;
         pa.rng[h][oi] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
     }
 }
@@ -1097,7 +1093,7 @@ static int ensure_paths(pm_ctx* c, RenderState* r, size_t npaths, int max_depth,
     r->pa_allocs.clear(); r->pa_cap = 0;
     auto al = [&](void** p, size_t bytes) -> int { HIPCHK(c, hipMalloc(p, bytes)); r->pa_allocs.push_back(*p); return PM_OK; };
     PathArrays& pa = r->pa;
-    float4** f4[] = {&pa.ro[0], &pa.ro[1], &pa.rd[0], &pa.rd[1], &pa.beta[0], &pa.beta[1], &pa.lambda[0], &pa.lambda[1],
+    float4** f4[] = {&pa.ro[0], &pa.ro[1], &pa.rd[0], &pa.rd[1], &pa.beta[0], &pa.beta[1],
                      &pa.hit, &pa.sh_o, &pa.sh_d, &pa.sh_L, &pa.L, &pa.lambda_s, &pa.pdf};
     int rc;
     for (auto p : f4) if ((rc = al((void**)p, npaths * sizeof(float4)))) return rc;
