@@ -462,189 +462,289 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
             const uint2 r2 = pa.rng[g][i];
             rng.state = ((unsigned long long)r2.y << 32) | r2.x; rng.inc = rng_inc_of(rc, slot);
         }
-        // ---- medium event (EXT): a real collision inside the homogeneous medium before the surface is reached?
-        bool surface = true;                // false: the path ended or scattered in the medium
-        bool use_medium = false;
-        float sig_t[4] = {0.f, 0.f, 0.f, 0.f};
-        if (EXT && rc.medium_on) {
-            use_medium = true;
-            const f3 ro = mk3(ro4.x, ro4.y, ro4.z);
-            float sig_a[4], sig_s[4];
+        if constexpr (!EXT) {
+            // The plain kernel (hot in C2 / C4): surface vertices only.  Kept as its own straight-line version: the unified form
+            // below compiles to a slower kernel here (measured 14.2 -> 15.2 ms per C2 frame).
+            constexpr bool use_medium = false;
+            const float sig_t[4] = {0.f, 0.f, 0.f, 0.f};
+            if (prim_id == 0xFFFFFFFFu) {
+                if (!rc.sample_lights || specular) {
+                    const float4 L4 = pa.L[slot];           // only escaped rays touch L here (hits: the shadow kernel adds NEE)
+                    float L[4] = {L4.x, L4.y, L4.z, L4.w};
+                    for (int k = 0; k < rc.n_infinite; ++k) {
+                        const Spec4 le = light_L(sc, sc.lights[sc.infinite[k]], lam);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                sig_a[c] = dense_at(sc.pool, rc.med_sigma_a, lam[c]); sig_s[c] = dense_at(sc.pool, rc.med_sigma_s, lam[c]);
-                sig_t[c] = sig_a[c] + sig_s[c];
-            }
-            float t0, t1;
-            if (medium_segment(rc.med_bounds, ro, rd, prim_id == 0xFFFFFFFFu ? INFINITY : hv.y, &t0, &t1)) {
-                const float dlen = len3(rd), seg = (t1 - t0) * dlen;
-                const float u = rng_uniform(&rng), um = rng_uniform(&rng);
-                const float s = sig_t[0] > 0.0f ? -cr_log(1.0f - u) / sig_t[0] : INFINITY;
-                if (s < seg) {
-                    surface = false;
-                    if (!(um < sig_a[0] / sig_t[0])) {          // scattered (absorbed otherwise: the path ends here)
-                        const float T0 = cr_exp(-sig_t[0] * s);
+                        for (int c = 0; c < 4; ++c) L[c] += beta[c] * le.v[c];
+                    }
+                    pa.L[slot] = make_float4(L[0], L[1], L[2], L[3]);
+                }
+            } else if (EXT || depth != rc.max_depth) {
+                // ---- interaction
+                const uint32_t ref = sc.prim_ref[prim_id];
+                SurfInt si;
+                if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], mk3(ro4.x, ro4.y, ro4.z), rd, hv.y);
+                else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
+                // ---- emitted radiance of an area light on this primitive (simple_path.rs:156-158; EXT only)
+                if (EXT && sc.prim_light && (!rc.sample_lights || specular)) {
+                    const int li = sc.prim_light[prim_id];
+                    if (li >= 0) {
+                        const DLight lt = sc.lights[li];
+                        if (lt.two_sided || !(dot3(si.n, -rd) < 0.0f)) {
+                            const Spec4 le = light_L(sc, lt, lam);
+                            const float4 L4 = pa.L[slot];
+                            pa.L[slot] = make_float4(L4.x + beta[0] * le.v[0], L4.y + beta[1] * le.v[1], L4.z + beta[2] * le.v[2], L4.w + beta[3] * le.v[3]);
+                        }
+                    }
+                }
+                if (depth != rc.max_depth) {
+                depth++;
+                Bsdf bsdf = make_bsdf<EXT>(sc, pa, si, prim_id, lam, slot, hv.z, hv.w);
+                const f3 wo = -rd;
+                // ---- next-event estimation (simple_path.rs:182-213)
+                if (rc.sample_lights) {
+                    const float ul = rng_uniform(&rng);
+                    if (rc.n_lights > 0) {
+                        const float fi = ul * (float)rc.n_lights;
+                        int idx = fi > 0.0f ? (int)fminf(fi, 2147483520.0f) : 0;
+                        if (idx > rc.n_lights - 1) idx = rc.n_lights - 1;
+                        const float prob = 1.0f / (float)rc.n_lights;
+                        f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
+                        Spec4 Ls; f3 wi, p_light; float lpdf;
+                        const f3 pm = si_p(si);
+                        if (sample_light<EXT>(rc, sc, sc.lights[idx], pm, u2, lam, &Ls, &wi, &lpdf, &p_light) && !spec_zero(Ls) && lpdf > 0.0f) {
+                            Spec4 f = bsdf_eval(bsdf, wo, wi);
+                            const float ad = fabsf(dot3(wi, si.ns));
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) beta[c] *= cr_exp(-sig_t[c] * s) * sig_s[c] / (T0 * sig_s[0]);
-                        if (depth != rc.max_depth) {
-                            depth++;
-                            const f3 p = ro + rd * (t0 + s / dlen);
-                            const f3 wo = (-rd) / dlen;
-                            if (rc.sample_lights) {
-                                const float ul = rng_uniform(&rng);
-                                if (rc.n_lights > 0) {
-                                    const float fi = ul * (float)rc.n_lights;
-                                    int idx = fi > 0.0f ? (int)fminf(fi, 2147483520.0f) : 0;
-                                    if (idx > rc.n_lights - 1) idx = rc.n_lights - 1;
-                                    const float prob = 1.0f / (float)rc.n_lights;
-                                    f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
-                                    Spec4 Ls; f3 wi, p_light; float lpdf;
-                                    if (sample_light<EXT>(rc, sc, sc.lights[idx], p, u2, lam, &Ls, &wi, &lpdf, &p_light) && !spec_zero(Ls) && lpdf > 0.0f) {
-                                        const float f = henyey_greenstein(dot3(wo, wi), rc.med_g);
-                                        if (f != 0.0f) {
-                                            const f3 dir = p_light - p;
-                                            const float den = prob * lpdf;
-                                            float tr[4] = {1.f, 1.f, 1.f, 1.f};
-                                            float s0, s1;
-                                            if (medium_segment(rc.med_bounds, p, dir, 1.0f - 0.0001f, &s0, &s1)) {
-                                                const float sl = (s1 - s0) * len3(dir);
+                            for (int c = 0; c < 4; ++c) f.v[c] *= ad;
+                            if (!spec_zero(f)) {
+                                const f3 dir = p_light - pm;
+                                const f3 so = offset_ray_origin(si, dir);
+                                const float den = prob * lpdf;
+                                float tr[4] = {1.f, 1.f, 1.f, 1.f};
+                                float s0, s1;
+                                if (EXT && use_medium && medium_segment(rc.med_bounds, so, dir, 1.0f - 0.0001f, &s0, &s1)) {
+                                    const float sl = (s1 - s0) * len3(dir);
 #pragma unroll
-                                                for (int c = 0; c < 4; ++c) tr[c] = cr_exp(-sig_t[c] * sl);
-                                            }
-                                            s_o = make_float4(p.x, p.y, p.z, 1.0f - 0.0001f); s_d = dir;
-                                            s_L = make_float4(beta[0] * f * Ls.v[0] * tr[0] / den, beta[1] * f * Ls.v[1] * tr[1] / den,
-                                                              beta[2] * f * Ls.v[2] * tr[2] / den, beta[3] * f * Ls.v[3] * tr[3] / den);
-                                            want_shadow = true;
-                                        }
-                                    }
+                                    for (int c = 0; c < 4; ++c) tr[c] = cr_exp(-sig_t[c] * sl);
                                 }
-                            }
-                            f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
-                            float ppdf;
-                            const f3 wi = sample_henyey_greenstein(wo, rc.med_g, u2, &ppdf);
-                            if (ppdf != 0.0f && !(beta[0] == 0.0f && beta[1] == 0.0f && beta[2] == 0.0f && beta[3] == 0.0f) &&
-                                !dead_end(rc, depth, false)) {
-                                c_o = p; c_d = wi; c_misc = (uint32_t)depth;      // specular_bounce = false
-                                cont = true;
+                                s_o = make_float4(so.x, so.y, so.z, 1.0f - 0.0001f); s_d = dir;
+                                if (EXT && use_medium)
+                                    s_L = make_float4(beta[0] * f.v[0] * Ls.v[0] * tr[0] / den, beta[1] * f.v[1] * Ls.v[1] * tr[1] / den,
+                                                      beta[2] * f.v[2] * Ls.v[2] * tr[2] / den, beta[3] * f.v[3] * Ls.v[3] * tr[3] / den);
+                                else
+                                    s_L = make_float4(beta[0] * f.v[0] * Ls.v[0] / den, beta[1] * f.v[1] * Ls.v[1] / den,
+                                                      beta[2] * f.v[2] * Ls.v[2] / den, beta[3] * f.v[3] * Ls.v[3] / den);
+                                want_shadow = true;
                             }
                         }
+                    }
+                }
+                // ---- continue the path (simple_path.rs:215-265)
+                f3 wi_next = mk3(0.f, 0.f, 0.f);
+                bool ok = false;
+                if (rc.sample_bsdf) {
+                    const float uc = rng_uniform(&rng);
+                    f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
+                    BsdfSample bs;
+                    if (bsdf_sample(bsdf, wo, uc, u2, &bs)) {
+                        const float ad = fabsf(dot3(bs.wi, si.ns));
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) beta[c] *= bs.value.v[c] * ad / bs.pdf;
+                        specular = (bs.flags & PM_BXDF_SPECULAR) != 0;
+                        wi_next = bs.wi; ok = true;
                     }
                 } else {
-                    const float Tm0 = cr_exp(-sig_t[0] * seg);       // passed through: T_maj over the pdf of doing so
+                    const int fl = bsdf_flags(bsdf);
+                    f3 wi; float spdf;
+                    f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
+                    if ((fl & PM_BXDF_REFLECTION) && (fl & PM_BXDF_TRANSMISSION)) { wi = sample_uniform_sphere(u2); spdf = PM_INV_4PI; }
+                    else {
+                        wi = sample_uniform_hemisphere(u2); spdf = PM_INV_2PI;
+                        const float pr = dot3(wo, si.n) * dot3(wi, si.n);
+                        if (((fl & PM_BXDF_REFLECTION) && pr < 0.0f) || ((fl & PM_BXDF_TRANSMISSION) && pr > 0.0f)) wi = -wi;
+                    }
+                    const Spec4 f = bsdf_eval(bsdf, wo, wi);
+                    const float ad = fabsf(dot3(wi, si.ns));
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) beta[c] *= cr_exp(-sig_t[c] * seg) / Tm0;
+                    for (int c = 0; c < 4; ++c) beta[c] *= f.v[c] * ad / spdf;
+                    specular = false;
+                    wi_next = wi; ok = true;
+                }
+                if (ok && !(beta[0] == 0.0f && beta[1] == 0.0f && beta[2] == 0.0f && beta[3] == 0.0f) && !dead_end(rc, depth, specular)) {
+                    c_o = offset_ray_origin(si, wi_next); c_d = wi_next;
+                    c_misc = (uint32_t)depth | (specular ? 1u << 8 : 0u);
+                    cont = true;
+                }
                 }
             }
-        }
-        if (!surface) {
-        } else if (prim_id == 0xFFFFFFFFu) {
-            if (!rc.sample_lights || specular) {
-                const float4 L4 = pa.L[slot];           // only escaped rays touch L here (hits: the shadow kernel adds NEE)
-                float L[4] = {L4.x, L4.y, L4.z, L4.w};
-                for (int k = 0; k < rc.n_infinite; ++k) {
-                    const Spec4 le = light_L(sc, sc.lights[sc.infinite[k]], lam);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) L[c] += beta[c] * le.v[c];
-                }
-                pa.L[slot] = make_float4(L[0], L[1], L[2], L[3]);
-            }
-        } else if (EXT || depth != rc.max_depth) {
-            // ---- interaction
-            const uint32_t ref = sc.prim_ref[prim_id];
+        } else {
+            // ---- What kind of path vertex is this?  A real collision inside the homogeneous medium (EXT), a surface hit, or none
+            // (escaped / absorbed / last vertex).  The two kinds of vertex then share ONE next-event estimation below - light
+            // sampling, shadow-ray set-up and transmittance are the same code, only f (phase function or BSDF x |cos|) and the ray
+            // origin differ - so a wave with both kinds runs that code once (it was duplicated per kind: PMC 0.41 active lanes).
+            bool surface = true;                // false: the path ended or scattered in the medium
+            bool use_medium = false;
+            bool vtx = false, vtx_medium = false;
+            f3 vp = mk3(0.f, 0.f, 0.f), wo = mk3(0.f, 0.f, 0.f);
             SurfInt si;
-            if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], mk3(ro4.x, ro4.y, ro4.z), rd, hv.y);
-            else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
-            // ---- emitted radiance of an area light on this primitive (simple_path.rs:156-158; EXT only)
-            if (EXT && sc.prim_light && (!rc.sample_lights || specular)) {
-                const int li = sc.prim_light[prim_id];
-                if (li >= 0) {
-                    const DLight lt = sc.lights[li];
-                    if (lt.two_sided || !(dot3(si.n, -rd) < 0.0f)) {
-                        const Spec4 le = light_L(sc, lt, lam);
-                        const float4 L4 = pa.L[slot];
-                        pa.L[slot] = make_float4(L4.x + beta[0] * le.v[0], L4.y + beta[1] * le.v[1], L4.z + beta[2] * le.v[2], L4.w + beta[3] * le.v[3]);
+            Bsdf bsdf;
+            float sig_t[4] = {0.f, 0.f, 0.f, 0.f};
+            if (EXT && rc.medium_on) {
+                use_medium = true;
+                const f3 ro = mk3(ro4.x, ro4.y, ro4.z);
+                float sig_a[4], sig_s[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    sig_a[c] = dense_at(sc.pool, rc.med_sigma_a, lam[c]); sig_s[c] = dense_at(sc.pool, rc.med_sigma_s, lam[c]);
+                    sig_t[c] = sig_a[c] + sig_s[c];
+                }
+                float t0, t1;
+                if (medium_segment(rc.med_bounds, ro, rd, prim_id == 0xFFFFFFFFu ? INFINITY : hv.y, &t0, &t1)) {
+                    const float dlen = len3(rd), seg = (t1 - t0) * dlen;
+                    const float u = rng_uniform(&rng), um = rng_uniform(&rng);
+                    const float s = sig_t[0] > 0.0f ? -cr_log(1.0f - u) / sig_t[0] : INFINITY;
+                    if (s < seg) {
+                        surface = false;
+                        if (!(um < sig_a[0] / sig_t[0])) {          // scattered (absorbed otherwise: the path ends here)
+                            const float T0 = cr_exp(-sig_t[0] * s);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) beta[c] *= cr_exp(-sig_t[c] * s) * sig_s[c] / (T0 * sig_s[0]);
+                            if (depth != rc.max_depth) {
+                                depth++;
+                                vtx = true; vtx_medium = true;
+                                vp = ro + rd * (t0 + s / dlen);
+                                wo = (-rd) / dlen;
+                            }
+                        }
+                    } else {
+                        const float Tm0 = cr_exp(-sig_t[0] * seg);       // passed through: T_maj over the pdf of doing so
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) beta[c] *= cr_exp(-sig_t[c] * seg) / Tm0;
                     }
                 }
             }
-            if (depth != rc.max_depth) {
-            depth++;
-            Bsdf bsdf = make_bsdf<EXT>(sc, pa, si, prim_id, lam, slot, hv.z, hv.w);
-            const f3 wo = -rd;
-            // ---- next-event estimation (simple_path.rs:182-213)
-            if (rc.sample_lights) {
-                const float ul = rng_uniform(&rng);
-                if (rc.n_lights > 0) {
-                    const float fi = ul * (float)rc.n_lights;
-                    int idx = fi > 0.0f ? (int)fminf(fi, 2147483520.0f) : 0;
-                    if (idx > rc.n_lights - 1) idx = rc.n_lights - 1;
-                    const float prob = 1.0f / (float)rc.n_lights;
-                    f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
-                    Spec4 Ls; f3 wi, p_light; float lpdf;
-                    const f3 pm = si_p(si);
-                    if (sample_light<EXT>(rc, sc, sc.lights[idx], pm, u2, lam, &Ls, &wi, &lpdf, &p_light) && !spec_zero(Ls) && lpdf > 0.0f) {
-                        Spec4 f = bsdf_eval(bsdf, wo, wi);
-                        const float ad = fabsf(dot3(wi, si.ns));
+            if (!surface) {
+            } else if (prim_id == 0xFFFFFFFFu) {
+                if (!rc.sample_lights || specular) {
+                    const float4 L4 = pa.L[slot];           // only escaped rays touch L here (hits: the shadow kernel adds NEE)
+                    float L[4] = {L4.x, L4.y, L4.z, L4.w};
+                    for (int k = 0; k < rc.n_infinite; ++k) {
+                        const Spec4 le = light_L(sc, sc.lights[sc.infinite[k]], lam);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) f.v[c] *= ad;
-                        if (!spec_zero(f)) {
-                            const f3 dir = p_light - pm;
-                            const f3 so = offset_ray_origin(si, dir);
-                            const float den = prob * lpdf;
-                            float tr[4] = {1.f, 1.f, 1.f, 1.f};
-                            float s0, s1;
-                            if (EXT && use_medium && medium_segment(rc.med_bounds, so, dir, 1.0f - 0.0001f, &s0, &s1)) {
-                                const float sl = (s1 - s0) * len3(dir);
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) tr[c] = cr_exp(-sig_t[c] * sl);
-                            }
-                            s_o = make_float4(so.x, so.y, so.z, 1.0f - 0.0001f); s_d = dir;
-                            if (EXT && use_medium)
-                                s_L = make_float4(beta[0] * f.v[0] * Ls.v[0] * tr[0] / den, beta[1] * f.v[1] * Ls.v[1] * tr[1] / den,
-                                                  beta[2] * f.v[2] * Ls.v[2] * tr[2] / den, beta[3] * f.v[3] * Ls.v[3] * tr[3] / den);
-                            else
-                                s_L = make_float4(beta[0] * f.v[0] * Ls.v[0] / den, beta[1] * f.v[1] * Ls.v[1] / den,
-                                                  beta[2] * f.v[2] * Ls.v[2] / den, beta[3] * f.v[3] * Ls.v[3] / den);
-                            want_shadow = true;
+                        for (int c = 0; c < 4; ++c) L[c] += beta[c] * le.v[c];
+                    }
+                    pa.L[slot] = make_float4(L[0], L[1], L[2], L[3]);
+                }
+            } else if (EXT || depth != rc.max_depth) {
+                // ---- interaction
+                const uint32_t ref = sc.prim_ref[prim_id];
+                if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], mk3(ro4.x, ro4.y, ro4.z), rd, hv.y);
+                else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
+                // ---- emitted radiance of an area light on this primitive (simple_path.rs:156-158; EXT only)
+                if (EXT && sc.prim_light && (!rc.sample_lights || specular)) {
+                    const int li = sc.prim_light[prim_id];
+                    if (li >= 0) {
+                        const DLight lt = sc.lights[li];
+                        if (lt.two_sided || !(dot3(si.n, -rd) < 0.0f)) {
+                            const Spec4 le = light_L(sc, lt, lam);
+                            const float4 L4 = pa.L[slot];
+                            pa.L[slot] = make_float4(L4.x + beta[0] * le.v[0], L4.y + beta[1] * le.v[1], L4.z + beta[2] * le.v[2], L4.w + beta[3] * le.v[3]);
                         }
                     }
                 }
-            }
-            // ---- continue the path (simple_path.rs:215-265)
-            f3 wi_next = mk3(0.f, 0.f, 0.f);
-            bool ok = false;
-            if (rc.sample_bsdf) {
-                const float uc = rng_uniform(&rng);
-                f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
-                BsdfSample bs;
-                if (bsdf_sample(bsdf, wo, uc, u2, &bs)) {
-                    const float ad = fabsf(dot3(bs.wi, si.ns));
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) beta[c] *= bs.value.v[c] * ad / bs.pdf;
-                    specular = (bs.flags & PM_BXDF_SPECULAR) != 0;
-                    wi_next = bs.wi; ok = true;
+                if (depth != rc.max_depth) {
+                    depth++;
+                    bsdf = make_bsdf<EXT>(sc, pa, si, prim_id, lam, slot, hv.z, hv.w);
+                    vtx = true;
+                    vp = si_p(si);
+                    wo = -rd;
                 }
-            } else {
-                const int fl = bsdf_flags(bsdf);
-                f3 wi; float spdf;
-                f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
-                if ((fl & PM_BXDF_REFLECTION) && (fl & PM_BXDF_TRANSMISSION)) { wi = sample_uniform_sphere(u2); spdf = PM_INV_4PI; }
-                else {
-                    wi = sample_uniform_hemisphere(u2); spdf = PM_INV_2PI;
-                    const float pr = dot3(wo, si.n) * dot3(wi, si.n);
-                    if (((fl & PM_BXDF_REFLECTION) && pr < 0.0f) || ((fl & PM_BXDF_TRANSMISSION) && pr > 0.0f)) wi = -wi;
-                }
-                const Spec4 f = bsdf_eval(bsdf, wo, wi);
-                const float ad = fabsf(dot3(wi, si.ns));
+            }
+            if (vtx) {
+                // ---- next-event estimation (simple_path.rs:182-213; the medium vertex evaluates the phase function instead)
+                if (rc.sample_lights) {
+                    const float ul = rng_uniform(&rng);
+                    if (rc.n_lights > 0) {
+                        const float fi = ul * (float)rc.n_lights;
+                        int idx = fi > 0.0f ? (int)fminf(fi, 2147483520.0f) : 0;
+                        if (idx > rc.n_lights - 1) idx = rc.n_lights - 1;
+                        const float prob = 1.0f / (float)rc.n_lights;
+                        f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
+                        Spec4 Ls; f3 wi, p_light; float lpdf;
+                        if (sample_light<EXT>(rc, sc, sc.lights[idx], vp, u2, lam, &Ls, &wi, &lpdf, &p_light) && !spec_zero(Ls) && lpdf > 0.0f) {
+                            Spec4 f;
+                            if (EXT && vtx_medium) f = spec_c(henyey_greenstein(dot3(wo, wi), rc.med_g));
+                            else {
+                                f = bsdf_eval(bsdf, wo, wi);
+                                const float ad = fabsf(dot3(wi, si.ns));
 #pragma unroll
-                for (int c = 0; c < 4; ++c) beta[c] *= f.v[c] * ad / spdf;
-                specular = false;
-                wi_next = wi; ok = true;
-            }
-            if (ok && !(beta[0] == 0.0f && beta[1] == 0.0f && beta[2] == 0.0f && beta[3] == 0.0f) && !dead_end(rc, depth, specular)) {
-                c_o = offset_ray_origin(si, wi_next); c_d = wi_next;
-                c_misc = (uint32_t)depth | (specular ? 1u << 8 : 0u);
-                cont = true;
-            }
+                                for (int c = 0; c < 4; ++c) f.v[c] *= ad;
+                            }
+                            if (!spec_zero(f)) {
+                                const f3 dir = p_light - vp;
+                                const f3 so = (EXT && vtx_medium) ? vp : offset_ray_origin(si, dir);
+                                const float den = prob * lpdf;
+                                float tr[4] = {1.f, 1.f, 1.f, 1.f};
+                                float s0, s1;
+                                if (EXT && use_medium && medium_segment(rc.med_bounds, so, dir, 1.0f - 0.0001f, &s0, &s1)) {
+                                    const float sl = (s1 - s0) * len3(dir);
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c) tr[c] = cr_exp(-sig_t[c] * sl);
+                                }
+                                s_o = make_float4(so.x, so.y, so.z, 1.0f - 0.0001f); s_d = dir;
+                                if (EXT && use_medium)
+                                    s_L = make_float4(beta[0] * f.v[0] * Ls.v[0] * tr[0] / den, beta[1] * f.v[1] * Ls.v[1] * tr[1] / den,
+                                                      beta[2] * f.v[2] * Ls.v[2] * tr[2] / den, beta[3] * f.v[3] * Ls.v[3] * tr[3] / den);
+                                else
+                                    s_L = make_float4(beta[0] * f.v[0] * Ls.v[0] / den, beta[1] * f.v[1] * Ls.v[1] / den,
+                                                      beta[2] * f.v[2] * Ls.v[2] / den, beta[3] * f.v[3] * Ls.v[3] / den);
+                                want_shadow = true;
+                            }
+                        }
+                    }
+                }
+                // ---- continue the path (simple_path.rs:215-265; the medium vertex samples the phase function)
+                f3 wi_next = mk3(0.f, 0.f, 0.f);
+                bool ok = false;
+                if (EXT && vtx_medium) {
+                    f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
+                    float ppdf;
+                    wi_next = sample_henyey_greenstein(wo, rc.med_g, u2, &ppdf);
+                    ok = ppdf != 0.0f;
+                    specular = false;
+                } else if (rc.sample_bsdf) {
+                    const float uc = rng_uniform(&rng);
+                    f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
+                    BsdfSample bs;
+                    if (bsdf_sample(bsdf, wo, uc, u2, &bs)) {
+                        const float ad = fabsf(dot3(bs.wi, si.ns));
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) beta[c] *= bs.value.v[c] * ad / bs.pdf;
+                        specular = (bs.flags & PM_BXDF_SPECULAR) != 0;
+                        wi_next = bs.wi; ok = true;
+                    }
+                } else {
+                    const int fl = bsdf_flags(bsdf);
+                    f3 wi; float spdf;
+                    f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
+                    if ((fl & PM_BXDF_REFLECTION) && (fl & PM_BXDF_TRANSMISSION)) { wi = sample_uniform_sphere(u2); spdf = PM_INV_4PI; }
+                    else {
+                        wi = sample_uniform_hemisphere(u2); spdf = PM_INV_2PI;
+                        const float pr = dot3(wo, si.n) * dot3(wi, si.n);
+                        if (((fl & PM_BXDF_REFLECTION) && pr < 0.0f) || ((fl & PM_BXDF_TRANSMISSION) && pr > 0.0f)) wi = -wi;
+                    }
+                    const Spec4 f = bsdf_eval(bsdf, wo, wi);
+                    const float ad = fabsf(dot3(wi, si.ns));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) beta[c] *= f.v[c] * ad / spdf;
+                    specular = false;
+                    wi_next = wi; ok = true;
+                }
+                if (ok && !(beta[0] == 0.0f && beta[1] == 0.0f && beta[2] == 0.0f && beta[3] == 0.0f) && !dead_end(rc, depth, specular)) {
+                    c_o = (EXT && vtx_medium) ? vp : offset_ray_origin(si, wi_next); c_d = wi_next;
+                    c_misc = (uint32_t)depth | (specular ? 1u << 8 : 0u);
+                    cont = true;
+                }
             }
         }
     }
