@@ -982,9 +982,8 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
         // ---- triangles: pre-filter, candidates queued for the exact round.  The culling distance becomes a fraction.
         FlatCull cull; cull.cn = tcull; cull.cd = 1.0f;
         const float KD = PM_PRE_K * D, R2 = 2.0f * R, epsb_ray = 8e-7f * __fmaf_rn(9.0f, R, D);
-#if PM_FLAT_UNROLL > 1
-#pragma unroll PM_FLAT_UNROLL
-#endif
+        constexpr int kUnroll = ANY ? 1 : PM_FLAT_UNROLL;      // (the any-hit loop leaves early: not unrollable)
+#pragma unroll kUnroll
         for (uint32_t i = 0; i < fs.n_tri; ++i) {
             // a certain hit always lowers the culling fraction, so "was there one" is read off it instead of being tracked
             // (tracking it makes the loop body branchier: measured 10 % of the kernel)
