@@ -448,6 +448,9 @@ struct SlowWriter {
 // makes as many exact-test trips as its busiest lane has candidates, so those rays are NOT given a deeper queue (measured:
 // depth 6 costs 14 %) but handed to the slow list.
 #define PM_FLAT_CAND_MAX 4
+#ifndef PM_FLAT_ANY_CHUNK
+#define PM_FLAT_ANY_CHUNK 16      /* any-hit sweep: the wave may leave between chunks of this many entries (4 / 8 / 16 measured: 10.2 / 9.65 / 9.45 ms) */
+#endif
 #ifndef PM_FLAT_UNROLL
 #define PM_FLAT_UNROLL 4       /* triangle loop of the sweep: four table entries per scalar-load wait (1 / 2 / 4 / 8 measured: closest
                                   sweep of the C2 frame 16.87 / 16.43 / 16.25 / 16.33 ms; registers unchanged) */
@@ -982,13 +985,20 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
         // ---- triangles: pre-filter, candidates queued for the exact round.  The culling distance becomes a fraction.
         FlatCull cull; cull.cn = tcull; cull.cd = 1.0f;
         const float KD = PM_PRE_K * D, R2 = 2.0f * R, epsb_ray = 8e-7f * __fmaf_rn(9.0f, R, D);
-        constexpr int kUnroll = ANY ? 1 : PM_FLAT_UNROLL;      // (the any-hit loop leaves early: not unrollable)
-#pragma unroll kUnroll
-        for (uint32_t i = 0; i < fs.n_tri; ++i) {
+        // the table in chunks of 8 entries: an any-hit wave leaves between chunks once all its rays are decided (closest hit:
+        // every live ray sweeps the whole table); inside a chunk the loop is unrolled, PM_FLAT_UNROLL entries per scalar-load wait
+        constexpr uint32_t kChunk = ANY ? (uint32_t)PM_FLAT_ANY_CHUNK : 0x10000u;       // (closest hit: one chunk)
+        for (uint32_t i0 = 0; i0 < fs.n_tri; i0 += kChunk) {
+        if (ANY) {
+            sure = !(cull.cn == tcull && cull.cd == 1.0f);
+            if (!__any(live && !slow && !(found || sure))) break;
+        }
+        const uint32_t i1 = i0 + kChunk < fs.n_tri ? i0 + kChunk : fs.n_tri;
+#pragma unroll PM_FLAT_UNROLL
+        for (uint32_t i = i0; i < i1; ++i) {
             // a certain hit always lowers the culling fraction, so "was there one" is read off it instead of being tracked
             // (tracking it makes the loop body branchier: measured 10 % of the kernel)
             if (ANY) sure = !(cull.cn == tcull && cull.cd == 1.0f);
-            if (ANY && (i & 7u) == 0u && !__any(live && !slow && !(found || sure))) break;   // (closest hit: every live ray sweeps the whole table)
             const cuint4_p e = as_uniform(reinterpret_cast<const uint4*>(fs.tris + i));
             const uint4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3];
             if (live && !slow && !(ANY && (found || sure))) {
@@ -1010,6 +1020,7 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
                     } else slow = true;         // one candidate too many: the second pass redoes this ray exactly
                 }
             }
+        }
         }
         sure = !(cull.cn == tcull && cull.cd == 1.0f);
         // ---- exact round: the queued triangles, in the order they were met, minus the certain hits whose t bracket starts
