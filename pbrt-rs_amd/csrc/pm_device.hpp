@@ -727,7 +727,10 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                 if (sp == 0) ended = true;
                 else {
                     --sp;
-                    cur = sp < PM_LDS_STACK ? lds[sp * stride] : spill[sp - PM_LDS_STACK];
+                    // (written so that the common case is a plain ds_read: `sp < N ? lds[..] : spill[..]` compiles to ONE flat
+                    // load through a selected address, which goes the slow way round and waits on every memory counter)
+                    cur = lds[(sp < PM_LDS_STACK ? sp : PM_LDS_STACK - 1) * stride];
+                    if (__builtin_expect(sp >= PM_LDS_STACK, 0)) cur = spill[sp - PM_LDS_STACK];
                     pm = cur.y & 0xFFu;
                 }
             }
