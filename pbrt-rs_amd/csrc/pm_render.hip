@@ -289,8 +289,10 @@ __global__ __launch_bounds__(TB) void shadow_fix_kernel(PmFlatScene fs, SceneArr
 // ------------------------------------------------------------------------------------------ shade
 __device__ __forceinline__ Spec4 light_L(const SceneArrays& sc, const DLight& l, const float* lam) {
     Spec4 r;
+    float t[4];
+    dense_at4(sc.pool, l.table, lam, t);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r.v[i] = dense_at(sc.pool, l.table, lam[i]) * l.scale;
+    for (int i = 0; i < 4; ++i) r.v[i] = t[i] * l.scale;
     return r;
 }
 
@@ -337,9 +339,8 @@ __device__ __forceinline__ uint32_t block_append(bool want, uint32_t* __restrict
 // may terminate the secondary wavelengths (pdfw is updated in registers and in the path state)
 // TEX: the scene has textured materials (compiled into the EXT shade kernel only); (u, v) = the hit's parametric coordinates
 template <bool TEX>
-__device__ __forceinline__ Bsdf make_bsdf(const SceneArrays& sc, const PathArrays& pa, const SurfInt& si, uint32_t prim_id,
-                                          const float* lam, uint32_t slot, float u = 0.0f, float v = 0.0f) {
-    const DMaterial mat = sc.materials[sc.prim_material[prim_id]];
+__device__ __forceinline__ Bsdf make_bsdf(const SceneArrays& sc, const PathArrays& pa, const SurfInt& si, const DMaterial& mat,
+                                          uint32_t ref, const float* lam, uint32_t slot, float u = 0.0f, float v = 0.0f) {
     Bsdf bsdf;
     bsdf.type = mat.type;
     if (mat.type == PM_MAT_DIFFUSE) {
@@ -347,7 +348,6 @@ __device__ __forceinline__ Bsdf make_bsdf(const SceneArrays& sc, const PathArray
         if (TEX && mat.texture == PM_TEX_CHECKERBOARD) {
             // st of the hit: lerped vertex uv of a patch that carries them, else the shape's own (u, v); then UvMapping::map
             f2 st; st.x = u; st.y = v;
-            const uint32_t ref = sc.prim_ref[prim_id];
             if ((ref >> 30) != PM_PRIM_SPHERE) {
                 const DShadePatch& sp = sc.patches[ref & 0x3FFFFFFFu];
                 if (sp.flags & 4u) {
@@ -359,8 +359,10 @@ __device__ __forceinline__ Bsdf make_bsdf(const SceneArrays& sc, const PathArray
             const float s = mat.su * st.x + mat.du, t = mat.sv * st.y + mat.dv;
             second = (((int)floorf(s) + (int)floorf(t)) & 1) != 0;
         }
+        float refl[4];
+        spectrum_at4(sc.pool, second ? mat.spec2 : mat.spec, lam, refl);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) bsdf.refl.v[c] = clampf(spectrum_at(sc.pool, second ? mat.spec2 : mat.spec, lam[c]), 0.0f, 1.0f);
+        for (int c = 0; c < 4; ++c) bsdf.refl.v[c] = clampf(refl[c], 0.0f, 1.0f);
         bsdf.eta = 1.0f; bsdf.tr.ax = 0.0f; bsdf.tr.ay = 0.0f;
     } else {
         bsdf.refl = spec_c(0.0f);
@@ -444,24 +446,25 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
     float4 l4 = make_float4(0.f, 0.f, 0.f, 0.f);
     Rng rng; rng.state = 0ull; rng.inc = 0ull;
     const bool live = i < n_in;
-    const float4 rd4 = live ? nt_load(pa.rd[g] + i) : make_float4(0.f, 0.f, 0.f, __uint_as_float(PM_DEAD));
+    // everything this vertex has at its queue index is read in ONE group (a padded entry of a ragged window reads words that
+    // mean nothing and are not used): read after the PM_DEAD test, these loads were a second round trip behind the first
+    float4 rd4 = make_float4(0.f, 0.f, 0.f, __uint_as_float(PM_DEAD)), ro4 = rd4, hv = rd4, b4 = rd4;
+    uint2 r2 = make_uint2(0u, 0u);
+    if (live) {
+        rd4 = nt_load(pa.rd[g] + i); ro4 = nt_load(pa.ro[g] + i); hv = nt_load(pa.hit + i); b4 = nt_load(pa.beta[g] + i);
+        r2 = pa.rng[g][i];
+    }
     const uint32_t mw = __float_as_uint(rd4.w);
     if (live && mw != PM_DEAD) {
-        const float4 ro4 = nt_load(pa.ro[g] + i);
         slot = __float_as_uint(ro4.w);
-        const float4 hv = nt_load(pa.hit + i);
         const uint32_t prim_id = __float_as_uint(hv.x);
-        const float4 b4 = nt_load(pa.beta[g] + i);
         l4 = pa.lambda_s[slot];         // by slot: the wavelengths never change along a path, so they are not carried in the queue
         beta[0] = b4.x; beta[1] = b4.y; beta[2] = b4.z; beta[3] = b4.w;
         const float lam[4] = {l4.x, l4.y, l4.z, l4.w};
         int depth = (int)(mw & 0xFFu);
         bool specular = ((mw >> 8) & 1u) != 0u;
         const f3 rd = mk3(rd4.x, rd4.y, rd4.z);
-        {
-            const uint2 r2 = pa.rng[g][i];
-            rng.state = ((unsigned long long)r2.y << 32) | r2.x; rng.inc = rng_inc_of(rc, slot);
-        }
+        rng.state = ((unsigned long long)r2.y << 32) | r2.x; rng.inc = rng_inc_of(rc, slot);
         if constexpr (!EXT) {
             // The plain kernel (hot in C2 / C4): surface vertices only.  Kept as its own straight-line version: the unified form
             // below compiles to a slower kernel here (measured 14.2 -> 15.2 ms per C2 frame).
@@ -480,7 +483,9 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                 }
             } else if (EXT || depth != rc.max_depth) {
                 // ---- interaction
+                // (the material record is fetched beside the shading record, not behind the interaction's arithmetic)
                 const uint32_t ref = sc.prim_ref[prim_id];
+                const DMaterial mat = sc.materials[sc.prim_material[prim_id]];
                 SurfInt si;
                 if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], mk3(ro4.x, ro4.y, ro4.z), rd, hv.y);
                 else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                 }
                 if (depth != rc.max_depth) {
                 depth++;
-                Bsdf bsdf = make_bsdf<EXT>(sc, pa, si, prim_id, lam, slot, hv.z, hv.w);
+                Bsdf bsdf = make_bsdf<EXT>(sc, pa, si, mat, ref, lam, slot, hv.z, hv.w);
                 const f3 wo = -rd;
                 // ---- next-event estimation (simple_path.rs:182-213)
                 if (rc.sample_lights) {
@@ -593,11 +598,10 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                 use_medium = true;
                 const f3 ro = mk3(ro4.x, ro4.y, ro4.z);
                 float sig_a[4], sig_s[4];
+                dense_at4(sc.pool, rc.med_sigma_a, lam, sig_a);
+                dense_at4(sc.pool, rc.med_sigma_s, lam, sig_s);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    sig_a[c] = dense_at(sc.pool, rc.med_sigma_a, lam[c]); sig_s[c] = dense_at(sc.pool, rc.med_sigma_s, lam[c]);
-                    sig_t[c] = sig_a[c] + sig_s[c];
-                }
+                for (int c = 0; c < 4; ++c) sig_t[c] = sig_a[c] + sig_s[c];
                 float t0, t1;
                 if (medium_segment(rc.med_bounds, ro, rd, prim_id == 0xFFFFFFFFu ? INFINITY : hv.y, &t0, &t1)) {
                     const float dlen = len3(rd), seg = (t1 - t0) * dlen;
@@ -654,7 +658,7 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                 }
                 if (depth != rc.max_depth) {
                     depth++;
-                    bsdf = make_bsdf<EXT>(sc, pa, si, prim_id, lam, slot, hv.z, hv.w);
+                    bsdf = make_bsdf<EXT>(sc, pa, si, sc.materials[sc.prim_material[prim_id]], ref, lam, slot, hv.z, hv.w);
                     vtx = true;
                     vp = si_p(si);
                     wo = -rd;
@@ -804,7 +808,7 @@ __global__ __launch_bounds__(RB) void shade_rw_kernel(RenderConst rc, SceneArray
             SurfInt si;
             if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], ro, rd, hv.y);
             else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
-            const Bsdf bsdf = make_bsdf<false>(sc, pa, si, prim_id, lam, slot);
+            const Bsdf bsdf = make_bsdf<false>(sc, pa, si, sc.materials[sc.prim_material[prim_id]], ref, lam, slot);
             const f3 wo = -rd;
             const uint2 r2 = pa.rng[g][i];
             rng.state = ((unsigned long long)r2.y << 32) | r2.x; rng.inc = rng_inc_of(rc, slot);
@@ -858,9 +862,10 @@ __global__ __launch_bounds__(RB) void accumulate_kernel(RenderConst rc, SceneArr
         float rgb[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float sum = 0.0f;
+            float sum = 0.0f, sv[4];
+            dense_at4(sc.pool, rc.sensor_table + 471 * c, lam, sv);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) sum += dense_at(sc.pool, rc.sensor_table + 471 * c, lam[i]) * Lp[i];
+            for (int i = 0; i < 4; ++i) sum += sv[i] * Lp[i];
             rgb[c] = sum / 4.0f * rc.imaging_ratio;
         }
         float m = rgb[0]; if (!(rgb[1] < m)) m = rgb[1]; if (!(rgb[2] < m)) m = rgb[2];

@@ -134,6 +134,48 @@ PMD float spectrum_at(const float* __restrict__ pool, const DSpectrum& s, float 
     }
 }
 
+// The same at the four wavelengths of a sample: ONE switch on the kind and the table reads issued together (index clamped, value
+// selected afterwards).  Lane by lane the arithmetic is that of the scalar functions; done per wavelength, every table read sat
+// in its own guarded branch behind its own wait - ten serialised cache round trips per path vertex in shade_kernel.
+PMD void dense_at4(const float* __restrict__ pool, int table, const float* lam, float* out) {
+    int li[4];
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) li[c] = (int)roundf(lam[c]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = pool[table + (li[c] < 360 ? 360 : li[c] > 830 ? 830 : li[c]) - 360];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[c] = (li[c] >= 360 && li[c] <= 830) ? v[c] : 0.0f;
+}
+PMD void spectrum_at4(const float* __restrict__ pool, const DSpectrum& s, const float* lam, float* out) {
+    switch (s.kind) {
+        case PM_SPEC_CONSTANT:
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[c] = s.a;
+            break;
+        case PM_SPEC_DENSE: dense_at4(pool, s.table, lam, out); break;
+        case PM_SPEC_RGB_ALBEDO:
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[c] = sigmoid_poly(s.a, s.b, s.c, lam[c]);
+            break;
+        case PM_SPEC_RGB_UNBOUNDED:
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[c] = s.d * sigmoid_poly(s.a, s.b, s.c, lam[c]);
+            break;
+        case PM_SPEC_RGB_ILLUMINANT: {
+            float t[4];
+            dense_at4(pool, s.table, lam, t);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[c] = s.d * sigmoid_poly(s.a, s.b, s.c, lam[c]) * t[c];
+            break;
+        }
+        default:
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[c] = blackbody(lam[c], s.a) * s.b;
+            break;
+    }
+}
+
 PMD float sample_visible_wavelength(float u) { return 538.0f - 138.88889f * cr_atanh(0.85691062f - 1.827502f * u); }
 PMD float visible_pdf(float lambda) {
     if (lambda >= 360.0f && lambda <= 830.0f) { const float ch = cr_cosh(0.0072f * (lambda - 538.0f)); return 0.003939804f / (ch * ch); }
