@@ -529,8 +529,7 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                                 float s0, s1;
                                 if (EXT && use_medium && medium_segment(rc.med_bounds, so, dir, 1.0f - 0.0001f, &s0, &s1)) {
                                     const float sl = (s1 - s0) * len3(dir);
-#pragma unroll
-                                    for (int c = 0; c < 4; ++c) tr[c] = cr_exp(-sig_t[c] * sl);
+                                    cr_exp_neg4(sig_t, sl, tr);
                                 }
                                 s_o = make_float4(so.x, so.y, so.z, 1.0f - 0.0001f); s_d = dir;
                                 if (EXT && use_medium)
@@ -610,9 +609,10 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                     if (s < seg) {
                         surface = false;
                         if (!(um < sig_a[0] / sig_t[0])) {          // scattered (absorbed otherwise: the path ends here)
-                            const float T0 = cr_exp(-sig_t[0] * s);
+                            float T[4];
+                            cr_exp_neg4(sig_t, s, T);
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) beta[c] *= cr_exp(-sig_t[c] * s) * sig_s[c] / (T0 * sig_s[0]);
+                            for (int c = 0; c < 4; ++c) beta[c] *= T[c] * sig_s[c] / (T[0] * sig_s[0]);
                             if (depth != rc.max_depth) {
                                 depth++;
                                 vtx = true; vtx_medium = true;
@@ -621,9 +621,10 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                             }
                         }
                     } else {
-                        const float Tm0 = cr_exp(-sig_t[0] * seg);       // passed through: T_maj over the pdf of doing so
+                        float T[4];                                      // passed through: T_maj over the pdf of doing so
+                        cr_exp_neg4(sig_t, seg, T);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) beta[c] *= cr_exp(-sig_t[c] * seg) / Tm0;
+                        for (int c = 0; c < 4; ++c) beta[c] *= T[c] / T[0];
                     }
                 }
             }
@@ -692,8 +693,7 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                                 float s0, s1;
                                 if (EXT && use_medium && medium_segment(rc.med_bounds, so, dir, 1.0f - 0.0001f, &s0, &s1)) {
                                     const float sl = (s1 - s0) * len3(dir);
-#pragma unroll
-                                    for (int c = 0; c < 4; ++c) tr[c] = cr_exp(-sig_t[c] * sl);
+                                    cr_exp_neg4(sig_t, sl, tr);
                                 }
                                 s_o = make_float4(so.x, so.y, so.z, 1.0f - 0.0001f); s_d = dir;
                                 if (EXT && use_medium)

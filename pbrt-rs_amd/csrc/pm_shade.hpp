@@ -51,6 +51,16 @@ PMD float cr_atanh(float x) { return (float)atanh((double)x); }
 PMD float cr_cosh(float x) { return (float)cosh((double)x); }
 PMD float cr_exp(float x) { return (float)exp((double)x); }
 PMD float cr_log(float x) { return (float)log((double)x); }
+// exp(-k[c] * x) for the four wavelengths.  A grey medium has four equal coefficients, and equal arguments give equal results:
+// the three repeats are then copies (same bits), and the f64 exponential - the most expensive call of a medium vertex - runs once.
+PMD void cr_exp_neg4(const float* k, float x, float* out) {
+    out[0] = cr_exp(-k[0] * x);
+#pragma unroll
+    for (int c = 1; c < 4; ++c) {
+        out[c] = out[0];
+        if (k[c] != k[0]) out[c] = cr_exp(-k[c] * x);
+    }
+}
 
 #define PM_PI 3.14159265358979323846f
 #define PM_INV_PI 0.318309886183790671537767526745028724f
