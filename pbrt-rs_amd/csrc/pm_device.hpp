@@ -269,8 +269,12 @@ PMD int tri_prefilter_flat(f3 ro, f3 rd, float KD, float R2, f3 v0, f3 e1, f3 e2
                            float epsb_ray, FlatCull* cull, bool lower, float* ln, float* ld) {
     const f3 sv = ro - v0;
     const f3 m = fcross(sv, rd);
-    float uu = fdot(e2, m), vv = -fdot(e1, m), det = -fdot(rd, n), tt = fdot(sv, n);
-    if (det < 0.0f) { det = -det; uu = -uu; vv = -vv; tt = -tt; }
+    // back-facing: all four change sign.  As products with +-1 (exact): no divergent region in the sweep's inner loop, and the
+    // compiler knows the results canonical (after a masked negation it re-canonicalises them in front of its min / max)
+    const float d0 = fdot(rd, n);
+    const float sg = d0 > 0.0f ? -1.0f : 1.0f;
+    const float uu = fdot(e2, m) * sg, vv = fdot(e1, m) * -sg, tt = fdot(sv, n) * sg;
+    const float det = -d0 * sg;
     const float Sx = R2 + c1;
     const float tb = (KD * L) * Sx;
     const float ttau = kll * Sx;
@@ -1004,7 +1008,9 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
             if (ANY) sure = !(cull.cn == tcull && cull.cd == 1.0f);
             const cuint4_p e = as_uniform(reinterpret_cast<const uint4*>(fs.tris + i));
             const uint4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3];
-            if (live && !slow && !(ANY && (found || sure))) {
+            // (closest hit: no lane predicate around the test - an idle or slow lane computes along for nothing, its candidates
+            // are never used, and the loop body is five scalar instructions shorter; the counting build keeps the predicate)
+            if ((!ANY && !COUNT) || (live && !slow && !(ANY && (found || sure)))) {
                 if (COUNT) ctr->prims++;
                 float ln, ld;
                 const int cls = tri_prefilter_flat(ray.o, ray.d, KD, R2,
