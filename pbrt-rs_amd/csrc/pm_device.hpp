@@ -265,39 +265,51 @@ PMD int tri_prefilter(f3 ro, f3 rd, float R, float D, f3 v0, f3 v1, f3 v2, float
 // fraction cn / cd (cd > 0), "t beyond tcull" and "t_hi below tcull" are cross-multiplied, and a certain hit replaces the
 // fraction by its own ((tt + ttau) * 1.00001, det - tb).  The candidate's lower bound is the fraction (ln, ld).
 struct FlatCull { float cn, cd; };
-PMD int tri_prefilter_flat(f3 ro, f3 rd, float KD, float R2, f3 v0, f3 e1, f3 e2, f3 n, float L, float c1, float kll,
-                           float epsb_ray, FlatCull* cull, bool lower, float* ln, float* ld) {
+struct FlatTerms { float uu, vv, det, tt, tb, ttau, dp; };
+// the two halves of tri_prefilter_flat: "can this triangle be skipped" (the sweep's inner loop), and the rest for the few
+// that cannot (1 or 2 as below)
+PMD bool tri_reject_flat(f3 ro, f3 rd, float KD, float R2, f3 v0, f3 e1, f3 e2, f3 n, float L, float c1, float kll,
+                         const FlatCull& cull, FlatTerms* o) {
     const f3 sv = ro - v0;
     const f3 m = fcross(sv, rd);
     // back-facing: all four change sign.  As products with +-1 (exact): no divergent region in the sweep's inner loop, and the
     // compiler knows the results canonical (after a masked negation it re-canonicalises them in front of its min / max)
     const float d0 = fdot(rd, n);
     const float sg = d0 > 0.0f ? -1.0f : 1.0f;
-    const float uu = fdot(e2, m) * sg, vv = fdot(e1, m) * -sg, tt = fdot(sv, n) * sg;
-    const float det = -d0 * sg;
+    o->uu = fdot(e2, m) * sg; o->vv = fdot(e1, m) * -sg; o->tt = fdot(sv, n) * sg;
+    o->det = -d0 * sg;
     const float Sx = R2 + c1;
-    const float tb = (KD * L) * Sx;
-    const float ttau = kll * Sx;
-    const float dp = det + tb;
-    const bool reject = (uu < -tb) | (vv < -tb) | (uu + vv > dp + tb) | (tt < -ttau) | ((tt - ttau) * cull->cd > cull->cn * dp);
-    if (reject) return 0;
+    o->tb = (KD * L) * Sx;
+    o->ttau = kll * Sx;
+    o->dp = o->det + o->tb;
+    return (o->uu < -o->tb) | (o->vv < -o->tb) | (o->uu + o->vv > o->dp + o->tb) | (o->tt < -o->ttau) |
+           ((o->tt - o->ttau) * cull.cd > cull.cn * o->dp);
+}
+PMD int tri_certain_flat(const FlatTerms& f, float c1, float epsb_ray, FlatCull* cull, bool lower, float* ln, float* ld) {
     *ln = 0.0f; *ld = 1.0f;
-    if ((uu > tb) & (vv > tb) & (uu + vv < (det - tb) - tb) & (det > 2.0f * tb) & (tt > ttau)) {
-        const float hn = (tt + ttau) * 1.00001f, hd = det - tb;
-        const float lo = (tt - ttau) * 0.99999f;
+    if ((f.uu > f.tb) & (f.vv > f.tb) & (f.uu + f.vv < (f.det - f.tb) - f.tb) & (f.det > 2.0f * f.tb) & (f.tt > f.ttau)) {
+        const float hn = (f.tt + f.ttau) * 1.00001f, hd = f.det - f.tb;
+        const float lo = (f.tt - f.ttau) * 0.99999f;
         // epsb >= the exact test's gamma(10) * sum of max-abs: 8e-7 * (5R + D + 4(S + L)) with S <= R + max|v0|
         const float epsb = __fmaf_rn(3.2e-6f, c1, epsb_ray);
-        if ((lo > epsb * dp) & (hn * cull->cd < cull->cn * hd)) {
+        if ((lo > epsb * f.dp) & (hn * cull->cd < cull->cn * hd)) {
             if (lower) { cull->cn = hn; cull->cd = hd; }
-            *ln = lo; *ld = dp;
+            *ln = lo; *ld = f.dp;
             return 2;
         }
     }
     return 1;
 }
+PMD int tri_prefilter_flat(f3 ro, f3 rd, float KD, float R2, f3 v0, f3 e1, f3 e2, f3 n, float L, float c1, float kll,
+                           float epsb_ray, FlatCull* cull, bool lower, float* ln, float* ld) {
+    FlatTerms ft;
+    if (tri_reject_flat(ro, rd, KD, R2, v0, e1, e2, n, L, c1, kll, *cull, &ft)) return 0;
+    return tri_certain_flat(ft, c1, epsb_ray, cull, lower, ln, ld);
+}
 PMD int tri_classify(float det, float uu, float vv, float tt, float L, float S, float R, float D, float tcull, float* t_hi,
                      float* t_lo) {
-    if (det < 0.0f) { det = -det; uu = -uu; vv = -vv; tt = -tt; }
+    const float sg = det < 0.0f ? -1.0f : 1.0f;         // (see tri_reject_flat)
+    det *= sg; uu *= sg; vv *= sg; tt *= sg;
     // error bounds.  The pre-filter itself works on differences (errors relative to L, S), but the exact test it must agree
     // with rounds absolute coordinates (errors relative to |ro| + |p| <= 2R + S + L), so the bounds carry Sx = S + R + L.
     const float Sx = S + R + L;
@@ -1012,15 +1024,17 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
             // are never used, and the loop body is five scalar instructions shorter; the counting build keeps the predicate)
             if ((!ANY && !COUNT) || (live && !slow && !(ANY && (found || sure)))) {
                 if (COUNT) ctr->prims++;
-                float ln, ld;
-                const int cls = tri_prefilter_flat(ray.o, ray.d, KD, R2,
-                                                   mk3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)),
-                                                   mk3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)),
-                                                   mk3(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z)),
-                                                   mk3(__uint_as_float(q3.x), __uint_as_float(q3.y), __uint_as_float(q3.z)),
-                                                   __uint_as_float(q0.w), __uint_as_float(q2.w), __uint_as_float(q3.w), epsb_ray,
-                                                   &cull, true, &ln, &ld);
-                if (cls != 0) {
+                FlatTerms ft;
+                // ONE masked region for everything behind the rejection (classification and the push into the queue): the
+                // common outcome - every lane rejects - then skips it with a single branch
+                if (!tri_reject_flat(ray.o, ray.d, KD, R2,
+                                     mk3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)),
+                                     mk3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)),
+                                     mk3(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z)),
+                                     mk3(__uint_as_float(q3.x), __uint_as_float(q3.y), __uint_as_float(q3.z)),
+                                     __uint_as_float(q0.w), __uint_as_float(q2.w), __uint_as_float(q3.w), cull, &ft)) {
+                    float ln, ld;
+                    (void)tri_certain_flat(ft, __uint_as_float(q2.w), epsb_ray, &cull, true, &ln, &ld);
                     if (qn < PM_FLAT_CAND_MAX) {
                         cand[qn * stride] = q1.w;
                         cand[(PM_FLAT_CAND_MAX + qn) * stride] = __float_as_uint(ln);
