@@ -1017,12 +1017,13 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
         for (uint32_t i = i0; i < i1; ++i) {
             // a certain hit always lowers the culling fraction, so "was there one" is read off it instead of being tracked
             // (tracking it makes the loop body branchier: measured 10 % of the kernel)
-            if (ANY) sure = !(cull.cn == tcull && cull.cd == 1.0f);
+            if (ANY && COUNT) sure = !(cull.cn == tcull && cull.cd == 1.0f);
             const cuint4_p e = as_uniform(reinterpret_cast<const uint4*>(fs.tris + i));
             const uint4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3];
-            // (closest hit: no lane predicate around the test - an idle or slow lane computes along for nothing, its candidates
-            // are never used, and the loop body is five scalar instructions shorter; the counting build keeps the predicate)
-            if ((!ANY && !COUNT) || (live && !slow && !(ANY && (found || sure)))) {
+            // (no lane predicate around the test: an idle, slow or - any hit - already occluded lane computes along for nothing;
+            // its candidates are never used, or are more occluders of a ray that has one.  The loop body is five to ten scalar
+            // instructions shorter for it.  The counting build keeps the predicate: its counters are the CPU mirror's.)
+            if (!COUNT || (live && !slow && !(ANY && (found || sure)))) {
                 if (COUNT) ctr->prims++;
                 FlatTerms ft;
                 // ONE masked region for everything behind the rejection (classification and the push into the queue): the
