@@ -6,6 +6,7 @@
 // N_node / N_prim that define the algorithmic bytes, and a device-independent check of the
 // traversal order logic.  The layout is re-declared here on purpose (no product header is included).
 #pragma once
+#include <cstring>
 #include <vector>
 
 #include "ref_scene.h"
@@ -189,6 +190,30 @@ struct WideWalker {
                         t.unit = unit;
                         ft.tris.push_back(t);
                     }
+                }
+            }
+        }
+        // table order (pm_layout.h, pm_build.cpp build_flat_table): groups of bit-equal v0 by first member; inside a group the
+        // next entry is the first unplaced one whose e1 is the current entry's e2, else the first unplaced one.  (The kernel
+        // reuses sv, sv x rd and the shared edge's product inside a group; recomputing them here gives the same bits.)
+        {
+            const std::vector<FlatTri> in = ft.tris;
+            auto same = [](const V3& a, const V3& b) { return std::memcmp(&a, &b, sizeof(V3)) == 0; };
+            std::vector<char> used(in.size(), 0);
+            ft.tris.clear();
+            for (size_t i = 0; i < in.size(); ++i) {
+                if (used[i]) continue;
+                std::vector<size_t> group;
+                for (size_t j = i; j < in.size(); ++j) if (!used[j] && same(in[j].v0, in[i].v0)) group.push_back(j);
+                long cur = -1;
+                for (size_t left = group.size(); left; --left) {
+                    long next = -1;
+                    if (cur >= 0)
+                        for (size_t j : group) if (!used[j] && same(in[j].e1, in[(size_t)cur].e2)) { next = (long)j; break; }
+                    if (next < 0)
+                        for (size_t j : group) if (!used[j]) { next = (long)j; break; }
+                    ft.tris.push_back(in[(size_t)next]);
+                    used[(size_t)next] = 1; cur = next;
                 }
             }
         }

@@ -381,6 +381,36 @@ void build_flat_table(Accel& acc, uint32_t max_prims) {
             }
         }
     }
+    // ---- order (pm_layout.h): groups of bit-equal v0 in the order of their first member; inside a group, chains along shared
+    // edges (the next entry is the first unplaced one whose e1 is the current e2; when there is none, the first unplaced one)
+    {
+        const std::vector<PmFlatTri> in = acc.flat_tris;
+        const size_t n = in.size();
+        auto same3 = [](const float* a, const float* b) { return std::memcmp(a, b, 3 * sizeof(float)) == 0; };
+        std::vector<char> used(n, 0);
+        std::vector<PmFlatTri> out;
+        out.reserve(n);
+        for (size_t i = 0; i < n; ++i) {
+            if (used[i]) continue;
+            std::vector<size_t> group;
+            for (size_t j = i; j < n; ++j) if (!used[j] && same3(in[j].v0, in[i].v0)) group.push_back(j);
+            size_t left = group.size();
+            long cur = -1;
+            while (left) {
+                long next = -1;
+                bool edge = false;
+                if (cur >= 0)
+                    for (size_t j : group) if (!used[j] && same3(in[j].e1, in[(size_t)cur].e2)) { next = (long)j; edge = true; break; }
+                if (next < 0)
+                    for (size_t j : group) if (!used[j]) { next = (long)j; break; }
+                PmFlatTri t = in[(size_t)next];
+                if (cur >= 0) t.unit |= PM_FLAT_SAME_V0 | (edge ? PM_FLAT_SAME_EDGE : 0u);
+                out.push_back(t);
+                used[(size_t)next] = 1; cur = next; --left;
+            }
+        }
+        acc.flat_tris = out;
+    }
     acc.flat_n[0] = (uint32_t)sph.size(); acc.flat_n[1] = (uint32_t)pat.size(); acc.flat_n[2] = (uint32_t)acc.flat_tris.size();
     acc.flat_units = sph;
     acc.flat_units.insert(acc.flat_units.end(), pat.begin(), pat.end());

@@ -268,15 +268,20 @@ struct FlatCull { float cn, cd; };
 struct FlatTerms { float uu, vv, det, tt, tb, ttau, dp; };
 // the two halves of tri_prefilter_flat: "can this triangle be skipped" (the sweep's inner loop), and the rest for the few
 // that cannot (1 or 2 as below)
+// (flags: PM_FLAT_SAME_V0 / PM_FLAT_SAME_EDGE of the table entry, wave-uniform; *sh: what the previous entry left - pm_layout.h)
+struct FlatShared { f3 sv, m; float e2m; };
 PMD bool tri_reject_flat(f3 ro, f3 rd, float KD, float R2, f3 v0, f3 e1, f3 e2, f3 n, float L, float c1, float kll,
-                         const FlatCull& cull, FlatTerms* o) {
-    const f3 sv = ro - v0;
-    const f3 m = fcross(sv, rd);
+                         uint32_t flags, FlatShared* sh, const FlatCull& cull, FlatTerms* o) {
+    if (!(flags & PM_FLAT_SAME_V0)) { sh->sv = ro - v0; sh->m = fcross(sh->sv, rd); }
+    float e1m;
+    if (flags & PM_FLAT_SAME_EDGE) e1m = sh->e2m; else e1m = fdot(e1, sh->m);
+    sh->e2m = fdot(e2, sh->m);
+    const f3 sv = sh->sv;
     // back-facing: all four change sign.  As products with +-1 (exact): no divergent region in the sweep's inner loop, and the
     // compiler knows the results canonical (after a masked negation it re-canonicalises them in front of its min / max)
     const float d0 = fdot(rd, n);
     const float sg = d0 > 0.0f ? -1.0f : 1.0f;
-    o->uu = fdot(e2, m) * sg; o->vv = fdot(e1, m) * -sg; o->tt = fdot(sv, n) * sg;
+    o->uu = sh->e2m * sg; o->vv = e1m * -sg; o->tt = fdot(sv, n) * sg;
     o->det = -d0 * sg;
     const float Sx = R2 + c1;
     o->tb = (KD * L) * Sx;
@@ -303,7 +308,8 @@ PMD int tri_certain_flat(const FlatTerms& f, float c1, float epsb_ray, FlatCull*
 PMD int tri_prefilter_flat(f3 ro, f3 rd, float KD, float R2, f3 v0, f3 e1, f3 e2, f3 n, float L, float c1, float kll,
                            float epsb_ray, FlatCull* cull, bool lower, float* ln, float* ld) {
     FlatTerms ft;
-    if (tri_reject_flat(ro, rd, KD, R2, v0, e1, e2, n, L, c1, kll, *cull, &ft)) return 0;
+    FlatShared sh;
+    if (tri_reject_flat(ro, rd, KD, R2, v0, e1, e2, n, L, c1, kll, 0u, &sh, *cull, &ft)) return 0;
     return tri_certain_flat(ft, c1, epsb_ray, cull, lower, ln, ld);
 }
 PMD int tri_classify(float det, float uu, float vv, float tt, float L, float S, float R, float D, float tcull, float* t_hi,
@@ -1007,6 +1013,9 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
         // the table in chunks of 8 entries: an any-hit wave leaves between chunks once all its rays are decided (closest hit:
         // every live ray sweeps the whole table); inside a chunk the loop is unrolled, PM_FLAT_UNROLL entries per scalar-load wait
         constexpr uint32_t kChunk = ANY ? (uint32_t)PM_FLAT_ANY_CHUNK : 0x10000u;       // (closest hit: one chunk)
+        // carried from entry to entry (a lane that tests an entry has tested all entries before it: the predicate of the
+        // counting build only ever turns off)
+        FlatShared shared; shared.sv = mk3(0.f, 0.f, 0.f); shared.m = mk3(0.f, 0.f, 0.f); shared.e2m = 0.f;
         for (uint32_t i0 = 0; i0 < fs.n_tri; i0 += kChunk) {
         if (ANY) {
             sure = !(cull.cn == tcull && cull.cd == 1.0f);
@@ -1033,11 +1042,11 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
                                      mk3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)),
                                      mk3(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z)),
                                      mk3(__uint_as_float(q3.x), __uint_as_float(q3.y), __uint_as_float(q3.z)),
-                                     __uint_as_float(q0.w), __uint_as_float(q2.w), __uint_as_float(q3.w), cull, &ft)) {
+                                     __uint_as_float(q0.w), __uint_as_float(q2.w), __uint_as_float(q3.w), q1.w, &shared, cull, &ft)) {
                     float ln, ld;
                     (void)tri_certain_flat(ft, __uint_as_float(q2.w), epsb_ray, &cull, true, &ln, &ld);
                     if (qn < PM_FLAT_CAND_MAX) {
-                        cand[qn * stride] = q1.w;
+                        cand[qn * stride] = q1.w & PM_FLAT_UNIT_MASK;
                         cand[(PM_FLAT_CAND_MAX + qn) * stride] = __float_as_uint(ln);
                         cand[(2 * PM_FLAT_CAND_MAX + qn) * stride] = __float_as_uint(ld);
                         ++qn;
@@ -1227,7 +1236,7 @@ PMD void deferred_fix(FlatScene fs, const uint4* __restrict__ prims, const uint4
             if (have && !(ANY && found)) { if (COUNT) ctr->prims++; fix_test_patch<COUNT>(prims, unit, false, ray, &tmax, &found, &hit, ctr); }
         }
         for (uint32_t i = 0; i < fs.n_tri; ++i) {
-            const uint32_t unit = fs.tris[i].unit;
+            const uint32_t unit = fs.tris[i].unit & PM_FLAT_UNIT_MASK;
             if (have && !(ANY && found)) {
                 if (COUNT) { ctr->prims++; ctr->exact++; }
                 const uint4* r = prims + unit;

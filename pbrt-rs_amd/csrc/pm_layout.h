@@ -54,6 +54,14 @@ static_assert(sizeof(PmTriRecord) == 16 * PM_UNITS_TRI && sizeof(PmPatchRecord) 
 // One 64-byte entry per triangle, derived from its record: e1 = v1 - v0, e2 = v2 - v0 (f32), n = e1 x e2 (f64 products,
 // rounded once), L = max |component| of e1, e2; c1 = max |component| of v0 + L and kll = (K * L) * L (K = 128 * 2^-24)
 // are the triangle's share of the pre-filter's error bounds; `unit` locates the 48-byte record for the exact test.
+// Table ORDER (pm_build.cpp build_flat_table): entries with bit-equal v0 are adjacent - a quad's two triangles, the faces
+// of a box around a corner - and inside such a group an entry whose e1 is the previous entry's e2 (the quad's diagonal)
+// follows it.  The top bits of `unit` say so, and the sweep then keeps what depends on v0 alone (ro - v0 and its cross
+// product with the direction: 9 operations) and the shared edge's triple product (3) from the previous entry.  Same
+// operands, same operations: the values are those of a fresh evaluation, bit for bit.
+#define PM_FLAT_SAME_V0 0x40000000u     /* v0 == the previous entry's v0 */
+#define PM_FLAT_SAME_EDGE 0x80000000u   /* ... and e1 == the previous entry's e2 */
+#define PM_FLAT_UNIT_MASK 0x3FFFFFFFu
 #define PM_FLAT_MAX_PRIMS 64
 struct alignas(16) PmFlatTri {
     float v0[3]; float L;
