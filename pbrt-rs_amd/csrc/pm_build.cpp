@@ -404,7 +404,8 @@ void build_flat_table(Accel& acc, uint32_t max_prims) {
                 if (next < 0)
                     for (size_t j : group) if (!used[j]) { next = (long)j; break; }
                 PmFlatTri t = in[(size_t)next];
-                if (cur >= 0) t.unit |= PM_FLAT_SAME_V0 | (edge ? PM_FLAT_SAME_EDGE : 0u);
+                if (cur >= 0)
+                    t.unit |= PM_FLAT_SAME_V0 | (edge ? PM_FLAT_SAME_EDGE : 0u) | (same3(t.n, in[(size_t)cur].n) ? PM_FLAT_SAME_N : 0u);
                 out.push_back(t);
                 used[(size_t)next] = 1; cur = next; --left;
             }

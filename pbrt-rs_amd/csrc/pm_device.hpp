@@ -268,21 +268,25 @@ struct FlatCull { float cn, cd; };
 struct FlatTerms { float uu, vv, det, tt, tb, ttau, dp; };
 // the two halves of tri_prefilter_flat: "can this triangle be skipped" (the sweep's inner loop), and the rest for the few
 // that cannot (1 or 2 as below)
-// (flags: PM_FLAT_SAME_V0 / PM_FLAT_SAME_EDGE of the table entry, wave-uniform; *sh: what the previous entry left - pm_layout.h)
-struct FlatShared { f3 sv, m; float e2m; };
+// (flags: PM_FLAT_SAME_V0 / _EDGE / _N of the table entry, wave-uniform; *sh: what the previous entry left - pm_layout.h)
+struct FlatShared { f3 sv, m; float e2m, sg, det, tt; };
 PMD bool tri_reject_flat(f3 ro, f3 rd, float KD, float R2, f3 v0, f3 e1, f3 e2, f3 n, float L, float c1, float kll,
                          uint32_t flags, FlatShared* sh, const FlatCull& cull, FlatTerms* o) {
     if (!(flags & PM_FLAT_SAME_V0)) { sh->sv = ro - v0; sh->m = fcross(sh->sv, rd); }
     float e1m;
     if (flags & PM_FLAT_SAME_EDGE) e1m = sh->e2m; else e1m = fdot(e1, sh->m);
     sh->e2m = fdot(e2, sh->m);
-    const f3 sv = sh->sv;
     // back-facing: all four change sign.  As products with +-1 (exact): no divergent region in the sweep's inner loop, and the
     // compiler knows the results canonical (after a masked negation it re-canonicalises them in front of its min / max)
-    const float d0 = fdot(rd, n);
-    const float sg = d0 > 0.0f ? -1.0f : 1.0f;
-    o->uu = sh->e2m * sg; o->vv = e1m * -sg; o->tt = fdot(sv, n) * sg;
-    o->det = -d0 * sg;
+    if (!(flags & PM_FLAT_SAME_N)) {
+        const float d0 = fdot(rd, n);
+        sh->sg = d0 > 0.0f ? -1.0f : 1.0f;
+        sh->det = -d0 * sh->sg;
+        sh->tt = fdot(sh->sv, n) * sh->sg;
+    }
+    const float sg = sh->sg;
+    o->uu = sh->e2m * sg; o->vv = e1m * -sg; o->tt = sh->tt;
+    o->det = sh->det;
     const float Sx = R2 + c1;
     o->tb = (KD * L) * Sx;
     o->ttau = kll * Sx;
@@ -1016,6 +1020,7 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
         // carried from entry to entry (a lane that tests an entry has tested all entries before it: the predicate of the
         // counting build only ever turns off)
         FlatShared shared; shared.sv = mk3(0.f, 0.f, 0.f); shared.m = mk3(0.f, 0.f, 0.f); shared.e2m = 0.f;
+        shared.sg = 1.0f; shared.det = 0.f; shared.tt = 0.f;
         for (uint32_t i0 = 0; i0 < fs.n_tri; i0 += kChunk) {
         if (ANY) {
             sure = !(cull.cn == tcull && cull.cd == 1.0f);

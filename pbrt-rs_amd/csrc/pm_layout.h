@@ -61,7 +61,8 @@ static_assert(sizeof(PmTriRecord) == 16 * PM_UNITS_TRI && sizeof(PmPatchRecord) 
 // operands, same operations: the values are those of a fresh evaluation, bit for bit.
 #define PM_FLAT_SAME_V0 0x40000000u     /* v0 == the previous entry's v0 */
 #define PM_FLAT_SAME_EDGE 0x80000000u   /* ... and e1 == the previous entry's e2 */
-#define PM_FLAT_UNIT_MASK 0x3FFFFFFFu
+#define PM_FLAT_SAME_N 0x20000000u      /* ... and n == the previous entry's n (a flat quad): rd.n, the facing and sv.n are kept too */
+#define PM_FLAT_UNIT_MASK 0x1FFFFFFFu
 #define PM_FLAT_MAX_PRIMS 64
 struct alignas(16) PmFlatTri {
     float v0[3]; float L;
