@@ -12,6 +12,7 @@
 // Rust's std calls on Linux) return for all but a small fraction of inputs.
 #pragma once
 #include "pm_device.hpp"
+#include "pm_crmath.hpp"
 
 namespace pmd {
 
@@ -47,8 +48,11 @@ PMD void cr_sincos_quarter(float x, float* sn, float* cs) {
     *sn = (float)(upper ? c : s);
     *cs = (float)(upper ? -s : c);
 }
-PMD float cr_atanh(float x) { return (float)atanh((double)x); }
-PMD float cr_cosh(float x) { return (float)cosh((double)x); }
+// atanh for |x| < 1 and cosh for |x| <= 2.2 - the wavelength sampler's arguments (|x| <= 0.9706; |x| <= 2.11) - written out in
+// pm_crmath.hpp: the f32 results equal (float)atanh((double)x) / (float)cosh((double)x) for every argument the sampler can
+// produce (checked exhaustively on the host, tests/test_crmath_cpu.py) at a quarter of the device library's f64 operations
+PMD float cr_atanh(float x) { return (float)pm_atanh_f32arg(x); }
+PMD float cr_cosh(float x) { return (float)pm_cosh_small((double)x); }
 PMD float cr_exp(float x) { return (float)exp((double)x); }
 PMD float cr_log(float x) { return (float)log((double)x); }
 // exp(-k[c] * x) for the four wavelengths.  A grey medium has four equal coefficients, and equal arguments give equal results:
