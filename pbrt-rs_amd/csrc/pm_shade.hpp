@@ -20,6 +20,9 @@ PMD float cr_sin(float x) { return (float)sin((double)x); }
 PMD float cr_cos(float x) { return (float)cos((double)x); }
 // sin and cos of one angle: one argument reduction instead of two
 PMD void cr_sincos(float x, float* sn, float* cs) { double s, c; sincos((double)x, &s, &c); *sn = (float)s; *cs = (float)c; }
+// ... of phi = 2 pi u (u in [0, 1)), the argument of every azimuth the sampling routines draw: pm_crmath.hpp, equal to the
+// above for each of the 2^23 values of u (tests/test_crmath_cpu.py)
+PMD void cr_sincos_2pi(float x, float* sn, float* cs) { double s, c; pm_sincos_2pi(x, &s, &c); *sn = (float)s; *cs = (float)c; }
 // ... for the concentric disk mapping, whose angle lies in [-pi/4, 3pi/4]: no argument reduction at all.  Taylor series in
 // double (|t| <= pi/4: the first neglected terms are 8e-20 and 2e-18), so the result is the correctly rounded float like
 // (float)sin((double)x) except where the exact value lies within ~2^-52 (relative) of a rounding boundary.
@@ -53,8 +56,10 @@ PMD void cr_sincos_quarter(float x, float* sn, float* cs) {
 // produce (checked exhaustively on the host, tests/test_crmath_cpu.py) at a quarter of the device library's f64 operations
 PMD float cr_atanh(float x) { return (float)pm_atanh_f32arg(x); }
 PMD float cr_cosh(float x) { return (float)pm_cosh_small((double)x); }
-PMD float cr_exp(float x) { return (float)exp((double)x); }
-PMD float cr_log(float x) { return (float)log((double)x); }
+// (pm_crmath.hpp: equal to (float)exp((double)x) for every f32 in [-104, 89] and beyond, to (float)log((double)x) for every
+// positive f32 - both checked exhaustively on the host)
+PMD float cr_exp(float x) { return (float)pm_exp_f32arg(x); }
+PMD float cr_log(float x) { return (float)pm_log_f32arg(x); }
 // exp(-k[c] * x) for the four wavelengths.  A grey medium has four equal coefficients, and equal arguments give equal results:
 // the three repeats are then copies (same bits), and the f64 exponential - the most expensive call of a medium vertex - runs once.
 PMD void cr_exp_neg4(const float* k, float x, float* out) {
@@ -202,14 +207,14 @@ PMD f3 sample_uniform_sphere(f2 u) {
     const float z = 1.0f - 2.0f * u.x;
     const float r = safe_sqrtf(1.0f - z * z);
     const float phi = 2.0f * PM_PI * u.y;
-    float sp, cp; cr_sincos(phi, &sp, &cp);
+    float sp, cp; cr_sincos_2pi(phi, &sp, &cp);
     return mk3(r * cp, r * sp, z);
 }
 PMD f3 sample_uniform_hemisphere(f2 u) {
     const float z = u.x;
     const float r = safe_sqrtf(1.0f - z * z);
     const float phi = 2.0f * PM_PI * u.y;
-    float sp, cp; cr_sincos(phi, &sp, &cp);
+    float sp, cp; cr_sincos_2pi(phi, &sp, &cp);
     return mk3(r * cp, r * sp, z);
 }
 PMD f2 sample_disk_concentric(f2 u) {
@@ -226,7 +231,7 @@ PMD f2 sample_disk_concentric(f2 u) {
 PMD f2 sample_disk_polar(f2 u) {
     const float r = sqrtf(u.x);
     const float th = 2.0f * PM_PI * u.y;
-    float st, ct; cr_sincos(th, &st, &ct);
+    float st, ct; cr_sincos_2pi(th, &st, &ct);
     f2 p; p.x = r * ct; p.y = r * st;
     return p;
 }
@@ -489,7 +494,7 @@ PMD f3 sample_henyey_greenstein(f3 wo, float g, f2 u, float* pdf) {
     else x = mk3(0.0f, wo.z, -wo.y) / sqrtf(wo.y * wo.y + wo.z * wo.z);
     y = cross3(wo, x);
     const float st = clampf(sin_theta, -1.0f, 1.0f), ct = clampf(cos_theta, -1.0f, 1.0f);
-    float sp, cp; cr_sincos(phi, &sp, &cp);
+    float sp, cp; cr_sincos_2pi(phi, &sp, &cp);
     *pdf = henyey_greenstein(cos_theta, g);
     return (st * cp) * x + (st * sp) * y + ct * wo;
 }
