@@ -1,14 +1,16 @@
-// Two f64 evaluations of raygen_kernel's wavelength sampling, written out instead of calling the device library.
+// The f64 transcendentals of the path, written out for the argument ranges the path uses instead of calling the device library.
 //
 // The reference computes `538 - 138.888889 * atanh(0.85691062 - 1.82750197 u)` and `0.0039398042 / cosh^2(0.0072 (lambda - 538))`
-// in f32 with the platform's libm (sampling/spectrum.rs:1004-1018).  Here - as in the oracle's correctly-rounded mode - the
-// value is the f64 function rounded to f32 (pm_shade.hpp).  The device library's f64 atanh / cosh are written for < 1 ulp over
+// in f32 with the platform's libm (sampling/spectrum.rs:1004-1018), azimuths as sin / cos of 2 pi u (sampling/routines.rs),
+// transmittance and free-flight distances with exp / log (media/medium.rs).  Here - as in the oracle's correctly-rounded mode -
+// the value is the f64 function rounded to f32 (pm_shade.hpp).  The device library's f64 routines are written for < 1 ulp over
 // the whole f64 range and cost ~125 f64 operations per call: 1062 of raygen_kernel's 2300 vector instructions were f64 (at half
-// the f32 issue rate), 673 of them additions of its double-double arithmetic.  The two forms below are exact enough for the
-// rounding to f32 (error <= ~2 ulp of f64: the rounded f32 differs from the correctly rounded one only where the exact value
-// lies within ~4e-16 (relative) of an f32 rounding boundary, i.e. for about 1 argument in 10^8) at ~35 and ~15 f64 operations.
-// tests/test_crmath_cpu.py compiles this header for the host and compares every argument the sampler can produce (2^23 values
-// of u) with glibc.
+// the f32 issue rate), 673 of them additions of its double-double arithmetic.  The forms below are exact enough for the
+// rounding to f32 (error <= 1.4 ulp of f64: the rounded f32 could differ from the correctly rounded one only where the exact
+// value lies within ~3e-16 (relative) of an f32 rounding boundary) at 15 to 40 f64 operations.  tests/test_crmath_cpu.py
+// compiles this header for the host and compares with glibc: every argument the samplers can produce (2^23 values of u) for
+// atanh, cosh and sincos, and - tests/native/crmath_check2.cpp, run in full once - every f32 of [-104, 89] for exp and every
+// positive f32 for log.  No f32 result differs.
 #pragma once
 #include <math.h>
 #include <stdint.h>
