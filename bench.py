@@ -358,6 +358,9 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup, work
         integ.clear()
         st = integ.render(window=window, samples=(s0, s1))
         if world > 1:
+            # the previous step's collective read `film` on RCCL's stream; it finished long ago (a whole render lies in
+            # between), and this makes that true by construction before the buffer is overwritten
+            torch.cuda.current_stream().synchronize()
             integ.film(out=film)
             if rows:
                 merged["film"] = pm.distributed.allgather_rows(film, sd.film["pixel_bounds"])
