@@ -426,6 +426,38 @@ __device__ __forceinline__ bool dead_end(const RenderConst& rc, int depth_after,
     return depth_after == rc.max_depth && !(rc.terminal_emission && (specular || !rc.sample_lights));
 }
 
+// Regroups the vertices of a block by kind (0, 1, then 2 = none): thread t afterwards holds the words of the vertex with rank t
+// in that order, and its kind.  Returns false - and changes nothing - when the block holds only one of the kinds 0 / 1.
+#define PM_XCH_WORDS 27
+__device__ __forceinline__ bool block_regroup(int* kind, uint32_t (&w)[PM_XCH_WORDS], uint32_t* xch /* [PM_XCH_WORDS * RB] */,
+                                              uint32_t* cnt /* [2 * RB / 64] */) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long b0 = __ballot(*kind == 0), b1 = __ballot(*kind == 1);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (lane == 0) { cnt[wave] = (uint32_t)__popcll(b0); cnt[RB / 64 + wave] = (uint32_t)__popcll(b1); }
+    __syncthreads();
+    uint32_t n0 = 0, n1 = 0, o0 = 0, o1 = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < RB / 64; ++k) {
+        const uint32_t c0 = cnt[k], c1 = cnt[RB / 64 + k];
+        if (k < wave) { o0 += c0; o1 += c1; }
+        n0 += c0; n1 += c1;
+    }
+    if (n0 == 0u || n1 == 0u) return false;            // (block-uniform)
+    if (*kind != 2) {
+        const uint32_t dest = *kind == 0 ? o0 + (uint32_t)__popcll(b0 & lt) : n0 + o1 + (uint32_t)__popcll(b1 & lt);
+#pragma unroll
+        for (int k = 0; k < PM_XCH_WORDS; ++k) xch[k * RB + dest] = w[k];
+    }
+    __syncthreads();
+    *kind = threadIdx.x < n0 ? 0 : (threadIdx.x < n0 + n1 ? 1 : 2);
+    if (*kind != 2) {
+#pragma unroll
+        for (int k = 0; k < PM_XCH_WORDS; ++k) w[k] = xch[k * RB + threadIdx.x];
+    }
+    return true;
+}
+
 // EXT: the scene holds area lights and / or the integrator is PM_INTEGRATOR_VOL_PATH with a medium set.  That code (emission on
 // a hit, shape sampling, the medium event as a third outcome beside "surface" and "escaped") is compiled only into the EXT
 // variant: it costs registers, and the plain variant is the hot kernel of the C2 / C4 frames.
@@ -445,6 +477,13 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
     float beta[4] = {0.f, 0.f, 0.f, 0.f};
     float4 l4 = make_float4(0.f, 0.f, 0.f, 0.f);
     Rng rng; rng.state = 0ull; rng.inc = 0ull;
+    // (EXT) what phase 2 of a vertex needs beyond the queue words; kind: 0 medium collision, 1 surface hit, 2 no vertex
+    int kind = 2, x_depth = 0;
+    uint32_t x_prim = 0xFFFFFFFFu;
+    bool x_spec = false;
+    float x_tmed = 0.f, x_lam[4] = {0.f, 0.f, 0.f, 0.f}, x_sig[4] = {0.f, 0.f, 0.f, 0.f};
+    __shared__ uint32_t xch[EXT ? PM_XCH_WORDS * RB : 1];
+    __shared__ uint32_t xch_cnt[2 * (RB / 64)];
     const bool live = i < n_in;
     // everything this vertex has at its queue index is read in ONE group (a padded entry of a ragged window reads words that
     // mean nothing and are not used): read after the PM_DEAD test, these loads were a second round trip behind the first
@@ -582,47 +621,41 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                 }
             }
         } else {
-            // ---- What kind of path vertex is this?  A real collision inside the homogeneous medium (EXT), a surface hit, or none
-            // (escaped / absorbed / last vertex).  The two kinds of vertex then share ONE next-event estimation below - light
-            // sampling, shadow-ray set-up and transmittance are the same code, only f (phase function or BSDF x |cos|) and the ray
-            // origin differ - so a wave with both kinds runs that code once (it was duplicated per kind: PMC 0.41 active lanes).
+            // ---- What kind of path vertex is this?  A real collision inside the homogeneous medium, a surface hit, or none
+            // (escaped / absorbed / last vertex).  Phase 1, here: the medium event and the radiance of an escaped ray.  Phase 2,
+            // below and outside this branch: the vertex itself.
+            x_prim = prim_id; x_depth = depth; x_spec = specular;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x_lam[c] = lam[c];
             bool surface = true;                // false: the path ended or scattered in the medium
-            bool use_medium = false;
-            bool vtx = false, vtx_medium = false;
-            f3 vp = mk3(0.f, 0.f, 0.f), wo = mk3(0.f, 0.f, 0.f);
-            SurfInt si;
-            Bsdf bsdf;
-            float sig_t[4] = {0.f, 0.f, 0.f, 0.f};
-            if (EXT && rc.medium_on) {
-                use_medium = true;
+            if (rc.medium_on) {
                 const f3 ro = mk3(ro4.x, ro4.y, ro4.z);
                 float sig_a[4], sig_s[4];
                 dense_at4(sc.pool, rc.med_sigma_a, lam, sig_a);
                 dense_at4(sc.pool, rc.med_sigma_s, lam, sig_s);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) sig_t[c] = sig_a[c] + sig_s[c];
+                for (int c = 0; c < 4; ++c) x_sig[c] = sig_a[c] + sig_s[c];
                 float t0, t1;
                 if (medium_segment(rc.med_bounds, ro, rd, prim_id == 0xFFFFFFFFu ? INFINITY : hv.y, &t0, &t1)) {
                     const float dlen = len3(rd), seg = (t1 - t0) * dlen;
                     const float u = rng_uniform(&rng), um = rng_uniform(&rng);
-                    const float s = sig_t[0] > 0.0f ? -cr_log(1.0f - u) / sig_t[0] : INFINITY;
+                    const float s = x_sig[0] > 0.0f ? -cr_log(1.0f - u) / x_sig[0] : INFINITY;
                     if (s < seg) {
                         surface = false;
-                        if (!(um < sig_a[0] / sig_t[0])) {          // scattered (absorbed otherwise: the path ends here)
+                        if (!(um < sig_a[0] / x_sig[0])) {          // scattered (absorbed otherwise: the path ends here)
                             float T[4];
-                            cr_exp_neg4(sig_t, s, T);
+                            cr_exp_neg4(x_sig, s, T);
 #pragma unroll
                             for (int c = 0; c < 4; ++c) beta[c] *= T[c] * sig_s[c] / (T[0] * sig_s[0]);
                             if (depth != rc.max_depth) {
-                                depth++;
-                                vtx = true; vtx_medium = true;
-                                vp = ro + rd * (t0 + s / dlen);
-                                wo = (-rd) / dlen;
+                                x_depth = depth + 1;
+                                kind = 0;
+                                x_tmed = t0 + s / dlen;
                             }
                         }
                     } else {
                         float T[4];                                      // passed through: T_maj over the pdf of doing so
-                        cr_exp_neg4(sig_t, seg, T);
+                        cr_exp_neg4(x_sig, seg, T);
 #pragma unroll
                         for (int c = 0; c < 4; ++c) beta[c] *= T[c] / T[0];
                     }
@@ -640,13 +673,60 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                     }
                     pa.L[slot] = make_float4(L[0], L[1], L[2], L[3]);
                 }
-            } else if (EXT || depth != rc.max_depth) {
-                // ---- interaction
+            } else kind = 1;
+        }
+    }
+    if constexpr (EXT) {
+        // ---- With a medium, a block's vertices are a mix of medium collisions and surface hits (C5: about 3 : 2), and their
+        // code differs (phase function against interaction + BSDF): a wave holding both runs both.  The block therefore REGROUPS
+        // its vertices by kind through LDS - collisions first, surface hits next, ended paths last - so that at most one of its
+        // four waves is mixed.  Which thread finishes a vertex changes nothing in the result: all state travels with it, and the
+        // film is accumulated by slot.
+        if (rc.medium_on) {
+            uint32_t w[PM_XCH_WORDS];
+            w[0] = slot; w[1] = x_prim; w[2] = __float_as_uint(hv.y); w[3] = __float_as_uint(hv.z); w[4] = __float_as_uint(hv.w);
+            w[5] = __float_as_uint(ro4.x); w[6] = __float_as_uint(ro4.y); w[7] = __float_as_uint(ro4.z);
+            w[8] = __float_as_uint(rd4.x); w[9] = __float_as_uint(rd4.y); w[10] = __float_as_uint(rd4.z);
+            w[11] = __float_as_uint(x_tmed);
+            w[12] = (uint32_t)x_depth | (x_spec ? 1u << 8 : 0u);
+            w[13] = (uint32_t)rng.state; w[14] = (uint32_t)(rng.state >> 32);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { w[15 + c] = __float_as_uint(beta[c]); w[19 + c] = __float_as_uint(x_lam[c]); w[23 + c] = __float_as_uint(x_sig[c]); }
+            if (block_regroup(&kind, w, xch, xch_cnt)) {
+                slot = w[0]; x_prim = w[1]; hv.y = __uint_as_float(w[2]); hv.z = __uint_as_float(w[3]); hv.w = __uint_as_float(w[4]);
+                ro4.x = __uint_as_float(w[5]); ro4.y = __uint_as_float(w[6]); ro4.z = __uint_as_float(w[7]);
+                rd4.x = __uint_as_float(w[8]); rd4.y = __uint_as_float(w[9]); rd4.z = __uint_as_float(w[10]);
+                x_tmed = __uint_as_float(w[11]);
+                x_depth = (int)(w[12] & 0xFFu); x_spec = ((w[12] >> 8) & 1u) != 0u;
+                rng.state = ((unsigned long long)w[14] << 32) | w[13]; rng.inc = rng_inc_of(rc, slot);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { beta[c] = __uint_as_float(w[15 + c]); x_lam[c] = __uint_as_float(w[19 + c]); x_sig[c] = __uint_as_float(w[23 + c]); }
+            }
+        }
+        if (kind != 2) {
+            const bool use_medium = rc.medium_on;
+            const bool vtx_medium = kind == 0;
+            const uint32_t prim_id = x_prim;
+            const f3 rd = mk3(rd4.x, rd4.y, rd4.z);
+            const float lam[4] = {x_lam[0], x_lam[1], x_lam[2], x_lam[3]};
+            const float sig_t[4] = {x_sig[0], x_sig[1], x_sig[2], x_sig[3]};
+            int depth = x_depth;
+            bool specular = x_spec;
+            bool vtx = vtx_medium;
+            f3 vp = mk3(0.f, 0.f, 0.f), wo = mk3(0.f, 0.f, 0.f);
+            SurfInt si;
+            Bsdf bsdf;
+            if (vtx_medium) {
+                vp = mk3(ro4.x, ro4.y, ro4.z) + rd * x_tmed;
+                wo = (-rd) / len3(rd);
+            } else {
+                // ---- interaction (fetching the material record here, beside the shading record, costs this kernel registers
+                // it does not have: 44.4 -> 48.5 ms per C5 frame)
                 const uint32_t ref = sc.prim_ref[prim_id];
                 if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], mk3(ro4.x, ro4.y, ro4.z), rd, hv.y);
                 else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
-                // ---- emitted radiance of an area light on this primitive (simple_path.rs:156-158; EXT only)
-                if (EXT && sc.prim_light && (!rc.sample_lights || specular)) {
+                // ---- emitted radiance of an area light on this primitive (simple_path.rs:156-158)
+                if (sc.prim_light && (!rc.sample_lights || specular)) {
                     const int li = sc.prim_light[prim_id];
                     if (li >= 0) {
                         const DLight lt = sc.lights[li];
