@@ -125,6 +125,20 @@ struct WideWalker {
         return 1;
     }
     // ---- the kernel's float pre-filter for spheres, operation for operation (pm_device.hpp sphere_prefilter)
+    // pm_device.hpp patch_prefilter: the padded box of the four corners against the ray, slab distances with relative slack
+    static bool patch_prefilter(V3 ro, V3 inv, float R, V3 p00, V3 p10, V3 p01, V3 p11, float tcull) {
+        const V3 lo(rmin(rmin(p00.x, p10.x), rmin(p01.x, p11.x)), rmin(rmin(p00.y, p10.y), rmin(p01.y, p11.y)),
+                    rmin(rmin(p00.z, p10.z), rmin(p01.z, p11.z)));
+        const V3 hi(rmax(rmax(p00.x, p10.x), rmax(p01.x, p11.x)), rmax(rmax(p00.y, p10.y), rmax(p01.y, p11.y)),
+                    rmax(rmax(p00.z, p10.z), rmax(p01.z, p11.z)));
+        const float pad = 1e-5f * rmax(rmax(maxabs(lo), maxabs(hi)), R);
+        const float ax = ((lo.x - pad) - ro.x) * inv.x, bx = ((hi.x + pad) - ro.x) * inv.x;
+        const float ay = ((lo.y - pad) - ro.y) * inv.y, by = ((hi.y + pad) - ro.y) * inv.y;
+        const float az = ((lo.z - pad) - ro.z) * inv.z, bz = ((hi.z + pad) - ro.z) * inv.z;
+        const float tn = rmax(rmax(rmin(ax, bx), rmin(ay, by)), rmax(rmin(az, bz), 0.0f));
+        const float tf = rmin(rmin(rmax(ax, bx), rmax(ay, by)), rmin(rmax(az, bz), tcull));
+        return tn <= tf * 1.00001f;
+    }
     static bool sphere_prefilter(V3 ro, V3 rd, float R, float D, const float* m, float radius, float m_norm, float t_norm, float tcull) {
         const float EPS = 4.76837158203125e-07f;
         V3 o(std::fmaf(m[0], ro.x, std::fmaf(m[1], ro.y, std::fmaf(m[2], ro.z, m[3]))),
@@ -247,10 +261,17 @@ struct WideWalker {
             const float* f = reinterpret_cast<const float*>(prims + (size_t)unit * 16);
             if (sphere_prefilter(ro, rd, R, D, f, f[12], f[18], f[19], tcull)) defer_prim(unit);
         }
-        for (uint32_t unit : ft.patches) {                  // reference arithmetic at once
-            if (slow || (any_hit && found)) break;
-            if (ctr) ctr->prims_tested++;
-            if (test_now(1, unit)) tcull = rmin(tcull, *ht);
+        {
+            auto rcp = [](float d) { return std::fabs(d) < 1e-18f ? std::copysign(1e18f, d) : 1.0f / d; };
+            const V3 inv(rcp(rd.x), rcp(rd.y), rcp(rd.z));
+            for (uint32_t unit : ft.patches) {              // closest hit: box pre-filter, what passes is deferred like a sphere
+                if (slow || (any_hit && found)) break;
+                if (ctr) ctr->prims_tested++;
+                if (any_hit) { if (test_now(1, unit)) tcull = rmin(tcull, *ht); continue; }     // any hit: reference arithmetic at once
+                const float* f = reinterpret_cast<const float*>(prims + (size_t)unit * 16);
+                if (patch_prefilter(ro, inv, R, V3(f[0], f[1], f[2]), V3(f[3], f[4], f[5]), V3(f[6], f[7], f[8]), V3(f[9], f[10], f[11]), tcull))
+                    defer_prim(unit | PATCH_TAG);
+            }
         }
         struct Cand { uint32_t unit; float ln, ld; };
         std::vector<Cand> cand;

@@ -340,6 +340,26 @@ PMD int tri_classify(float det, float uu, float vv, float tt, float L, float S, 
     return 1;
 }
 
+// ---- float pre-filter for bilinear patches (flat sweep): false = the ray misses the padded bounding box of the four corners
+// within [0, tcull].  A bilinear patch lies inside the convex hull of its corners, and the exact test (reference arithmetic,
+// ~300 instructions) accepts nothing that lies outside the surface by more than its own rounding, ~1e-6 of the coordinates
+// involved; the pad is 1e-4 of them, and the slab distances are compared with a relative slack of 1e-4 as well.  inv: the
+// finite reciprocals of the direction (safe_rcp_dir).  What passes is deferred to the second pass like a sphere.  The CPU
+// walker repeats these operations.
+PMD bool patch_prefilter(f3 ro, f3 inv, float R, f3 p00, f3 p10, f3 p01, f3 p11, float tcull) {
+    const f3 lo = mk3(fminf(fminf(p00.x, p10.x), fminf(p01.x, p11.x)), fminf(fminf(p00.y, p10.y), fminf(p01.y, p11.y)),
+                      fminf(fminf(p00.z, p10.z), fminf(p01.z, p11.z)));
+    const f3 hi = mk3(fmaxf(fmaxf(p00.x, p10.x), fmaxf(p01.x, p11.x)), fmaxf(fmaxf(p00.y, p10.y), fmaxf(p01.y, p11.y)),
+                      fmaxf(fmaxf(p00.z, p10.z), fmaxf(p01.z, p11.z)));
+    const float pad = 1e-5f * fmaxf(fmaxf(maxc3(abs3(lo)), maxc3(abs3(hi))), R);
+    const float ax = ((lo.x - pad) - ro.x) * inv.x, bx = ((hi.x + pad) - ro.x) * inv.x;
+    const float ay = ((lo.y - pad) - ro.y) * inv.y, by = ((hi.y + pad) - ro.y) * inv.y;
+    const float az = ((lo.z - pad) - ro.z) * inv.z, bz = ((hi.z + pad) - ro.z) * inv.z;
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tcull));
+    return tn <= tf * 1.00001f;
+}
+
 // ---- float pre-filter for spheres: false = the exact (interval) test cannot accept this sphere with t <= tcull.
 // The interval test costs ~1500 instructions and a wave pays for it as soon as ONE lane runs it, so spheres that pass are
 // not tested inside the walk: the (ray, sphere) pair goes to a global list and a second, dense kernel runs the exact
@@ -992,22 +1012,30 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
                     defer_prim(unit);
             }
         }
-        // ---- patches (PATCH: the scene has some; kernels for scenes without are compiled without the bilinear patch test,
-        // whose registers would cost the sweep a wave per SIMD): reference arithmetic at once
+        // ---- patches (PATCH: the scene has some).  Closest hit: the box pre-filter; what passes is deferred like a sphere (round
+        // 1 ran the reference arithmetic at once, for every ray and every patch: ~300 instructions each).  Any hit: still at
+        // once - shadow rays aim AT area lights, i.e. at patches, end a hair in front of them and so pass any box test; deferring
+        // them all was measured at twice the sweep's time (C5 shadow sweep 22 -> 43 ms).
         if (PATCH) {
+            const f3 pinv = mk3(safe_rcp_dir(ray.d.x), safe_rcp_dir(ray.d.y), safe_rcp_dir(ray.d.z));
             for (uint32_t i = 0; i < fs.n_patch; ++i) {
                 const uint32_t unit = as_uniform(fs.units)[fs.n_sphere + i];
                 if (live && !slow && !(ANY && found)) {
-                    if (COUNT) { ctr->prims++; ctr->exact++; }
+                    if (COUNT) ctr->prims++;
                     const cuint4_p r = as_uniform(prims + unit);
-                    const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-                    float t, u, v;
-                    if (intersect_patch(ray.o, ray.d, tmax, mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)),
-                                        mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y)),
-                                        mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x)),
-                                        mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w)), &t, &u, &v)) {
-                        tmax = t; tcull = fminf(tcull, t); found = true; hit.prim_id = r3.x; hit.t = t; hit.u = u; hit.v = v;
-                    }
+                    const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
+                    const f3 p00 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
+                    const f3 p10 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
+                    const f3 p01 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
+                    const f3 p11 = mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
+                    if (ANY) {
+                        if (COUNT) ctr->exact++;
+                        const uint4 r3 = r[3];
+                        float t, u, v;
+                        if (intersect_patch(ray.o, ray.d, tmax, p00, p10, p01, p11, &t, &u, &v)) {
+                            tmax = t; tcull = fminf(tcull, t); found = true; hit.prim_id = r3.x; hit.t = t; hit.u = u; hit.v = v;
+                        }
+                    } else if (patch_prefilter(ray.o, pinv, R, p00, p10, p01, p11, tcull)) defer_prim(unit | PM_DEFER_PATCH);
                 }
             }
         }
