@@ -44,6 +44,81 @@ def _scene(pm, seed):
     return prims, pos, idx, rng
 
 
+def _patch_scene(pm, seed, n_patches=28):
+    """mostly bilinear patches (twisted, flat, skinny), plus two spheres: the closest-hit sweep pre-filters every patch by its
+    padded box and defers what passes"""
+    rng = np.random.default_rng(100 + seed)
+    quads = []
+    for k in range(n_patches):
+        c = rng.uniform(-2.5, 2.5, 3)
+        e1 = rng.normal(size=3) * rng.uniform(0.05, 1.5)
+        e2 = rng.normal(size=3) * rng.uniform(0.05, 1.5)
+        twist = rng.normal(size=3) * (0.0 if k % 3 == 0 else rng.uniform(0.0, 0.5))       # every third patch is flat
+        quads.append([c, c + e1, c + e2, c + e1 + e2 + twist])
+    pos = np.asarray(quads, np.float32).reshape(-1, 3)
+    prims = [pm.BilinearPatchMesh(pos, np.arange(4 * n_patches, dtype=np.uint32).reshape(-1, 4))]
+    for _ in range(2):
+        m = np.eye(4, dtype=np.float32)
+        m[:3, 3] = rng.uniform(-2, 2, 3)
+        mi = np.eye(4, dtype=np.float32)
+        mi[:3, 3] = -m[:3, 3]
+        prims.append(pm.Sphere(0.5, -0.5, 0.5, 360.0, m, mi))
+    return prims, pos.reshape(-1, 4, 3), rng
+
+
+def _patch_rays(pm, quads, rng, n):
+    """rays through points p(u, v) ON the patches - interior, on the boundary (u or v exactly 0 / 1), a hair outside it - from
+    random origins, some starting on another patch (t ~ 0 candidates)"""
+    k = rng.integers(0, len(quads), n)
+    q = quads[k]
+    u = rng.random(n).astype(np.float32)
+    v = rng.random(n).astype(np.float32)
+    kind = rng.integers(0, 4, n)
+    u = np.where(kind == 1, np.round(u), u)                                  # on the edge u = 0 / 1
+    v = np.where(kind == 2, np.round(v), v)
+    u = np.where(kind == 3, np.where(u < 0.5, np.float32(-1e-6), np.float32(1.0 + 1e-6)), u)      # a hair outside
+    u, v = u[:, None], v[:, None]
+    target = (1 - u) * (1 - v) * q[:, 0] + u * (1 - v) * q[:, 1] + (1 - u) * v * q[:, 2] + u * v * q[:, 3]
+    o = (target + rng.normal(size=(n, 3)) * rng.uniform(0.3, 20.0, (n, 1))).astype(np.float32)
+    on = rng.random(n) < 0.2                                                 # origins on a patch
+    k2 = rng.integers(0, len(quads), n)
+    q2 = quads[k2]
+    o = np.where(on[:, None], (q2[:, 0] + q2[:, 3]) * np.float32(0.5), o).astype(np.float32)
+    rays = np.zeros(n, dtype=pm.RAY_DTYPE)
+    rays["o"] = o
+    rays["d"] = ((target - o) * rng.uniform(0.2, 3.0, (n, 1))).astype(np.float32)
+    rays["tmax"] = np.where(rng.random(n) < 0.3, rng.uniform(0.2, 1.5, n), np.inf).astype(np.float32)
+    return rays
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_flat_sweep_of_patches_equals_reference(pm, ora, seed):
+    import helpers
+    prims, quads, rng = _patch_scene(pm, seed)
+    agg = pm.GpuAggregate(prims, device_id=-1)
+    assert agg.info.flat_prims == agg.info.n_prims <= 64
+
+    class SD:
+        pass
+    sd = SD()
+    sd.prims = prims
+    sc = helpers.oracle_scene_from(sd, ora)
+    rays = np.concatenate([_patch_rays(pm, quads, rng, 120_000), pm.scenes.incoherent_rays(40_000, seed=seed, radius=6.0)])
+    ref, _ = sc.intersect(rays)
+    nb, pb = agg.node_buffer(), agg.prim_buffer()
+    flat, fc = ora.wide_trace(nb, pb, rays, flat=True)
+    assert 0.3 < (ref["prim_id"] != 0xFFFFFFFF).mean() < 0.99
+    same = flat["prim_id"] == ref["prim_id"]
+    assert (~same).sum() <= 4                                   # exact-t ties
+    assert np.array_equal(flat["t"].view(np.uint32), ref["t"].view(np.uint32))
+    assert np.array_equal(flat["u"][same].view(np.uint32), ref["u"][same].view(np.uint32))
+    # the box pre-filter does its job: far fewer exact tests than (ray, patch) pairs, and what it lets through includes every hit
+    assert fc["exact_tests"] < 0.35 * fc["prims_tested"]
+    occ, _ = ora.wide_trace(nb, pb, rays, any_hit=True, flat=True)
+    occ_ref, _ = sc.intersect_p(rays)
+    assert np.array_equal(occ.astype(bool), occ_ref.astype(bool))
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_flat_sweep_equals_reference(pm, ora, seed):
     import helpers

@@ -53,6 +53,55 @@ def test_flat_and_tree_kernels_equal_reference(pm, ora, monkeypatch, seed):
         del agg
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_flat_kernels_on_a_scene_of_patches(pm, ora, seed):
+    """28 bilinear patches + 2 spheres: closest hit through the box pre-filter and the second pass, any hit at once; hits
+    against the reference traversal, counters against the CPU mirror."""
+    import helpers
+    from test_flat_cpu import _patch_rays, _patch_scene
+    prims, quads, rng = _patch_scene(pm, seed)
+
+    class SD:
+        pass
+    sd = SD()
+    sd.prims = prims
+    sc = helpers.oracle_scene_from(sd, ora)
+    rays = np.concatenate([_patch_rays(pm, quads, rng, 300_000), pm.scenes.incoherent_rays(100_000, seed=seed, radius=6.0)])
+    ref, _ = sc.intersect(rays)
+    ref_a, _ = sc.intersect_p(rays)
+    agg = pm.GpuAggregate(prims)
+    assert agg.info.flat_prims == agg.info.n_prims
+    agg.set_counting(True)
+    agg.reset_counters()
+    gpu = agg.intersect(rays)
+    c = agg.counters()
+    cpu, cw = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays, flat=True)
+    assert np.array_equal(gpu["prim_id"], cpu["prim_id"])
+    assert np.array_equal(gpu["t"].view(np.uint32), cpu["t"].view(np.uint32))
+    for k in ("prims_tested", "exact_tests", "fallback_walks"):
+        assert c[k] == cw[k], (k, c, cw)
+    assert np.array_equal(gpu["t"].view(np.uint32), ref["t"].view(np.uint32))
+    assert (gpu["prim_id"] != ref["prim_id"]).sum() <= 4
+    same = gpu["prim_id"] == ref["prim_id"]
+    patch = same & (gpu["prim_id"] < len(quads))                # (u, v) of a patch hit: bit for bit
+    assert patch.sum() > 100_000
+    assert np.array_equal(gpu["u"][patch].view(np.uint32), ref["u"][patch].view(np.uint32))
+    assert np.array_equal(gpu["v"][patch].view(np.uint32), ref["v"][patch].view(np.uint32))
+    sph = same & (gpu["prim_id"] >= len(quads)) & (gpu["prim_id"] != 0xFFFFFFFF)      # of a sphere hit: acosf / atan2f, 1e-5
+    assert np.allclose(gpu["u"][sph], ref["u"][sph], atol=1e-5) and np.allclose(gpu["v"][sph], ref["v"][sph], atol=1e-5)
+    agg.reset_counters()
+    occ = agg.intersect_p(rays)
+    ca = agg.counters()
+    _, cwa = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays, any_hit=True, flat=True)
+    assert np.array_equal(occ.astype(bool), ref_a.astype(bool))
+    for k in ("prims_tested", "exact_tests", "fallback_walks"):
+        assert ca[k] == cwa[k], ("any", k, ca, cwa)
+    agg.set_counting(False)
+    # and without the counters (the kernels the renderer runs)
+    assert np.array_equal(agg.intersect(rays)["t"].view(np.uint32), ref["t"].view(np.uint32))
+    assert np.array_equal(agg.intersect_p(rays).astype(bool), ref_a.astype(bool))
+
+
 def test_cornell_film_flat_equals_tree(pm, monkeypatch):
     """The wavefront render of the C2 scene is the same film whether rays sweep the 35 primitives or walk their tree."""
     sd = pm.scenes.cornell_scene((96, 96))
