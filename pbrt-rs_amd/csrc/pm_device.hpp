@@ -941,11 +941,12 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
 // ---- scenes of at most PM_FLAT_MAX_PRIMS primitives: no tree.  Every wave takes 64 consecutive work items and sweeps the
 // whole flat table (pm_layout.h) in lock step: the records are wave-uniform (scalar loads), nothing diverges but the
 // bookkeeping, and there are no node steps.  The sweep kernel is kept LEAN - pre-filters, the exact triangle test and (only
-// in the variant for scenes that hold patches) the bilinear patch test - because its speed hangs on registers
+// in the any-hit variant for scenes that hold patches) the bilinear patch test - because its speed hangs on registers
 // (occupancy): every interval-arithmetic sphere test and every rare case goes to the second pass (deferred_fix), which
 // runs them with all lanes busy:
-//   * spheres that pass sphere_prefilter are DEFERRED: up to three per ray travel in the ray's list entry;
-//   * a fourth deferred sphere, a fifth triangle candidate, or exact tests that do not confirm what culling assumed make
+//   * spheres that pass sphere_prefilter and (closest hit) patches that pass patch_prefilter are DEFERRED: up to three per
+//     ray travel in the ray's list entry;
+//   * a fourth deferred primitive, a fifth triangle candidate, or exact tests that do not confirm what culling assumed make
 //     the ray SLOW: the second pass redoes it from scratch with exact tests only (counted in fallback).
 // Triangles go through tri_prefilter_flat into the candidate queue as in trace_persistent, then the exact round.
 using FlatScene = PmFlatScene;
@@ -986,7 +987,7 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
         }
         const float R = maxc3(abs3(ray.o)), D = maxc3(abs3(ray.d));
         float tmax = ray.tmax;
-        float tcull = ray.tmax;                     // spheres never lower it, patches do; triangles cull by the fraction below
+        float tcull = ray.tmax;                     // spheres never lower it, (any hit) patches do; triangles cull by the fraction below
         bool sure = false, found = false, slow = false;
         uint32_t qn = 0, d0 = PM_DEFER_NONE, d1 = PM_DEFER_NONE, d2 = PM_DEFER_NONE;
         HitRec hit; hit.prim_id = 0xFFFFFFFFu; hit.t = ray.tmax; hit.u = 0.0f; hit.v = 0.0f;
