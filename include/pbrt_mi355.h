@@ -275,6 +275,12 @@ int pm_debug_sample(pm_ctx* ctx, const PmRenderParams* params, int32_t px, int32
 int pm_debug_uniforms(pm_ctx* ctx, int32_t px, int32_t py, uint32_t seed, uint64_t sample_index, uint64_t dimension, int32_t n,
                       float* out);
 
+/* test hook: the device's transcendentals at n arguments (host pointers).  The reference calls f32 libm functions
+ * (sampling/spectrum.rs:1004-1018 atanh / cosh, sampling/routines.rs sin / cos of 2 pi u, media/medium.rs exp / ln); the device
+ * evaluates them in f64 and rounds once (csrc/pm_crmath.hpp).  which: 0 atanh (|x| < 1), 1 cosh (|x| <= 2.2), 2 exp, 3 log,
+ * 4 / 5 sin / cos of an azimuth in [0, 2 pi], 6 / 7 sin / cos of the concentric-disk angle in [-pi/4, 3 pi/4] */
+int pm_debug_math(pm_ctx* ctx, int32_t which, const float* x, int32_t n, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,6 +132,7 @@ SYMBOLS = {
     "pm_get_queue_counts": (C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     "pm_debug_sample": (C.c_int, [_P, C.POINTER(PmRenderParams), C.c_int32, C.c_int32, C.c_int32, _P]),
     "pm_debug_uniforms": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32, _P]),
+    "pm_debug_math": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P]),
     # include/pbrt_mi355_host.h
     "pmh_mat4_inverse": (C.c_int, [_P, _P]),
     "pmh_mat4_mul": (None, [_P, _P, _P]),

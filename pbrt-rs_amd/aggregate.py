@@ -164,6 +164,13 @@ class GpuAggregate:
         self._check(self._lib.pm_debug_uniforms(self._h, px, py, seed, sample_index, dimension, n, out.ctypes.data))
         return out
 
+    def debug_math(self, which, x):
+        """the device's f64-then-round transcendental `which` (include/pbrt_mi355.h pm_debug_math) at the f32 arguments x — test hook"""
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros(len(x), np.float32)
+        self._check(self._lib.pm_debug_math(self._h, which, x.ctypes.data, len(x), out.ctypes.data))
+        return out
+
     def last_kernel_ms(self):
         ms = C.c_float()
         self._check(self._lib.pm_last_kernel_ms(self._h, C.byref(ms)))

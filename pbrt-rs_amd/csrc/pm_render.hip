@@ -1513,6 +1513,42 @@ extern "C" int pm_debug_uniforms(pm_ctx* c, int32_t px, int32_t py, uint32_t see
     if (e != hipSuccess) return fail(c, PM_ERR_HIP, std::string("pm_debug_uniforms: ") + hipGetErrorString(e));
     return PM_OK;
 }
+__global__ void debug_math_kernel(int which, const float* __restrict__ x, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    float s = 0.0f, c = 0.0f, r = 0.0f;
+    switch (which) {
+        case 0: r = cr_atanh(v); break;
+        case 1: r = cr_cosh(v); break;
+        case 2: r = cr_exp(v); break;
+        case 3: r = cr_log(v); break;
+        case 4: cr_sincos_2pi(v, &s, &c); r = s; break;
+        case 5: cr_sincos_2pi(v, &s, &c); r = c; break;
+        case 6: cr_sincos_quarter(v, &s, &c); r = s; break;
+        default: cr_sincos_quarter(v, &s, &c); r = c; break;
+    }
+    out[i] = r;
+}
+extern "C" int pm_debug_math(pm_ctx* c, int32_t which, const float* x, int32_t n, float* out) {
+    if (!c || !x || !out || n < 0 || which < 0 || which > 7) return fail(c, PM_ERR_INVALID, "pm_debug_math: bad argument");
+    if (c->device < 0) return fail(c, PM_ERR_INVALID, "pm_debug_math: host-only context");
+    if (n == 0) return PM_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    float *dx = nullptr, *dout = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dx, (size_t)n * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&dout, (size_t)n * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(dx, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, (int)which, dx, (int)n, dout);
+        e = hipMemcpyAsync(out, dout, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dx);
+    if (dout) (void)hipFree(dout);
+    if (e != hipSuccess) return fail(c, PM_ERR_HIP, std::string("pm_debug_math: ") + hipGetErrorString(e));
+    return PM_OK;
+}
 extern "C" int pm_get_queue_counts(pm_ctx* c, uint64_t* closest, uint64_t* shadow, uint32_t cap, uint32_t* n_bounces) {
     if (!c || !c->render) return fail(c, PM_ERR_INVALID, "pm_get_queue_counts: nothing rendered");
     const RenderState* r = c->render;

@@ -251,6 +251,7 @@ extern "C" {
     pub fn pm_get_queue_counts(ctx: *mut pm_ctx, closest: *mut u64, shadow: *mut u64, cap: u32, n_bounces: *mut u32) -> i32;
     pub fn pm_debug_sample(ctx: *mut pm_ctx, params: *const PmRenderParams, px: i32, py: i32, sample_index: i32, out13: *mut f32) -> i32;
     pub fn pm_debug_uniforms(ctx: *mut pm_ctx, px: i32, py: i32, seed: u32, sample_index: u64, dimension: u64, n: i32, out: *mut f32) -> i32;
+    pub fn pm_debug_math(ctx: *mut pm_ctx, which: i32, x: *const f32, n: i32, out: *mut f32) -> i32;
 }
 
 // Layout guards: the sizes the C header asserts (include/pbrt_mi355.h, PM_STATIC_ASSERT block).  A field added on one side
