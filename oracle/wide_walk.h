@@ -255,24 +255,12 @@ struct WideWalker {
             if (test_prim(type, unit, ro, rd, t_max, &id, &t, &u, &v)) { t_max = t; found = true; *hid = id; *ht = t; *hu = u; *hv = v; return true; }
             return false;
         };
-        for (uint32_t unit : ft.spheres) {
-            if (slow) break;
-            if (ctr) ctr->prims_tested++;
-            const float* f = reinterpret_cast<const float*>(prims + (size_t)unit * 16);
-            if (sphere_prefilter(ro, rd, R, D, f, f[12], f[18], f[19], tcull)) defer_prim(unit);
-        }
-        {
-            auto rcp = [](float d) { return std::fabs(d) < 1e-18f ? std::copysign(1e18f, d) : 1.0f / d; };
-            const V3 inv(rcp(rd.x), rcp(rd.y), rcp(rd.z));
-            for (uint32_t unit : ft.patches) {              // closest hit: box pre-filter, what passes is deferred like a sphere
-                if (slow || (any_hit && found)) break;
+        if (any_hit)                                        // patches, any hit: reference arithmetic at once, before the triangles
+            for (uint32_t unit : ft.patches) {
+                if (slow || found) break;
                 if (ctr) ctr->prims_tested++;
-                if (any_hit) { if (test_now(1, unit)) tcull = rmin(tcull, *ht); continue; }     // any hit: reference arithmetic at once
-                const float* f = reinterpret_cast<const float*>(prims + (size_t)unit * 16);
-                if (patch_prefilter(ro, inv, R, V3(f[0], f[1], f[2]), V3(f[3], f[4], f[5]), V3(f[6], f[7], f[8]), V3(f[9], f[10], f[11]), tcull))
-                    defer_prim(unit | PATCH_TAG);
+                if (test_now(1, unit)) tcull = rmin(tcull, *ht);
             }
-        }
         struct Cand { uint32_t unit; float ln, ld; };
         std::vector<Cand> cand;
         FlatCull cull{tcull, 1.0f};
@@ -286,6 +274,28 @@ struct WideWalker {
                 if (cls == 2) sure = true;
                 if (cand.size() < CAND_MAX) cand.push_back(Cand{t.unit, ln, ld});
                 else slow = true;
+            }
+        }
+        // spheres and (closest hit) patches AFTER the triangles: pre-filters against the distance a certain triangle hit leaves
+        // (any hit: a decided ray skips them); what passes is deferred to the second pass
+        if (!(any_hit && (found || sure))) {
+            const float tcs = (cull.cn / cull.cd) * 1.00001f;
+            for (uint32_t unit : ft.spheres) {
+                if (slow) break;
+                if (ctr) ctr->prims_tested++;
+                const float* f = reinterpret_cast<const float*>(prims + (size_t)unit * 16);
+                if (sphere_prefilter(ro, rd, R, D, f, f[12], f[18], f[19], tcs)) defer_prim(unit);
+            }
+            if (!any_hit) {
+                auto rcp = [](float d) { return std::fabs(d) < 1e-18f ? std::copysign(1e18f, d) : 1.0f / d; };
+                const V3 inv(rcp(rd.x), rcp(rd.y), rcp(rd.z));
+                for (uint32_t unit : ft.patches) {
+                    if (slow) break;
+                    if (ctr) ctr->prims_tested++;
+                    const float* f = reinterpret_cast<const float*>(prims + (size_t)unit * 16);
+                    if (patch_prefilter(ro, inv, R, V3(f[0], f[1], f[2]), V3(f[3], f[4], f[5]), V3(f[6], f[7], f[8]), V3(f[9], f[10], f[11]), tcs))
+                        defer_prim(unit | PATCH_TAG);
+                }
             }
         }
         if (!slow) {

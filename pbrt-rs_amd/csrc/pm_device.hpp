@@ -998,45 +998,23 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
             else slow = true;
         };
 
-        // ---- spheres: float pre-filter; what passes is deferred
-        for (uint32_t i = 0; i < fs.n_sphere; ++i) {
-            const uint32_t unit = as_uniform(fs.units)[i];
-            if (live && !slow) {
-                if (COUNT) ctr->prims++;
-                const cuint4_p r = as_uniform(prims + unit);
-                float m[12];
-                const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
-                m[0] = __uint_as_float(r0.x); m[1] = __uint_as_float(r0.y); m[2] = __uint_as_float(r0.z); m[3] = __uint_as_float(r0.w);
-                m[4] = __uint_as_float(r1.x); m[5] = __uint_as_float(r1.y); m[6] = __uint_as_float(r1.z); m[7] = __uint_as_float(r1.w);
-                m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
-                if (sphere_prefilter(ray.o, ray.d, R, D, m, __uint_as_float(r3.x), __uint_as_float(r4.z), __uint_as_float(r4.w), tcull))
-                    defer_prim(unit);
-            }
-        }
-        // ---- patches (PATCH: the scene has some).  Closest hit: the box pre-filter; what passes is deferred like a sphere (round
-        // 1 ran the reference arithmetic at once, for every ray and every patch: ~300 instructions each).  Any hit: still at
-        // once - shadow rays aim AT area lights, i.e. at patches, end a hair in front of them and so pass any box test; deferring
-        // them all was measured at twice the sweep's time (C5 shadow sweep 22 -> 43 ms).
-        if (PATCH) {
-            const f3 pinv = mk3(safe_rcp_dir(ray.d.x), safe_rcp_dir(ray.d.y), safe_rcp_dir(ray.d.z));
+        // ---- patches, any hit (PATCH: the scene has some): the reference arithmetic at once - shadow rays aim AT area lights,
+        // i.e. at patches, end a hair in front of them and so pass any box test; deferring them all was measured at twice the
+        // sweep's time (C5 shadow sweep 22 -> 43 ms)
+        if (PATCH && ANY) {
             for (uint32_t i = 0; i < fs.n_patch; ++i) {
                 const uint32_t unit = as_uniform(fs.units)[fs.n_sphere + i];
-                if (live && !slow && !(ANY && found)) {
-                    if (COUNT) ctr->prims++;
+                if (live && !slow && !found) {
+                    if (COUNT) { ctr->prims++; ctr->exact++; }
                     const cuint4_p r = as_uniform(prims + unit);
-                    const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
-                    const f3 p00 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
-                    const f3 p10 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
-                    const f3 p01 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
-                    const f3 p11 = mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
-                    if (ANY) {
-                        if (COUNT) ctr->exact++;
-                        const uint4 r3 = r[3];
-                        float t, u, v;
-                        if (intersect_patch(ray.o, ray.d, tmax, p00, p10, p01, p11, &t, &u, &v)) {
-                            tmax = t; tcull = fminf(tcull, t); found = true; hit.prim_id = r3.x; hit.t = t; hit.u = u; hit.v = v;
-                        }
-                    } else if (patch_prefilter(ray.o, pinv, R, p00, p10, p01, p11, tcull)) defer_prim(unit | PM_DEFER_PATCH);
+                    const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+                    float t, u, v;
+                    if (intersect_patch(ray.o, ray.d, tmax, mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)),
+                                        mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y)),
+                                        mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x)),
+                                        mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w)), &t, &u, &v)) {
+                        tmax = t; tcull = fminf(tcull, t); found = true; hit.prim_id = r3.x; hit.t = t; hit.u = u; hit.v = v;
+                    }
                 }
             }
         }
@@ -1090,6 +1068,40 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
         }
         }
         sure = !(cull.cn == tcull && cull.cd == 1.0f);
+        // ---- spheres and (closest hit) patches: float pre-filters; what passes is deferred to the second pass.  AFTER the
+        // triangles: a certain triangle hit bounds the distance within which a sphere or a patch still matters (any hit: the ray
+        // is decided and skips them altogether) - tested first, against the ray's own t_max, twice as many were deferred.
+        const float tcs = (cull.cn / cull.cd) * 1.00001f;
+        for (uint32_t i = 0; i < fs.n_sphere; ++i) {
+            const uint32_t unit = as_uniform(fs.units)[i];
+            if (live && !slow && !(ANY && (found || sure))) {
+                if (COUNT) ctr->prims++;
+                const cuint4_p r = as_uniform(prims + unit);
+                float m[12];
+                const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+                m[0] = __uint_as_float(r0.x); m[1] = __uint_as_float(r0.y); m[2] = __uint_as_float(r0.z); m[3] = __uint_as_float(r0.w);
+                m[4] = __uint_as_float(r1.x); m[5] = __uint_as_float(r1.y); m[6] = __uint_as_float(r1.z); m[7] = __uint_as_float(r1.w);
+                m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
+                if (sphere_prefilter(ray.o, ray.d, R, D, m, __uint_as_float(r3.x), __uint_as_float(r4.z), __uint_as_float(r4.w), tcs))
+                    defer_prim(unit);
+            }
+        }
+        if (PATCH && !ANY) {        // (round 1 ran the reference arithmetic at once, for every ray and every patch: ~300 instructions each)
+            const f3 pinv = mk3(safe_rcp_dir(ray.d.x), safe_rcp_dir(ray.d.y), safe_rcp_dir(ray.d.z));
+            for (uint32_t i = 0; i < fs.n_patch; ++i) {
+                const uint32_t unit = as_uniform(fs.units)[fs.n_sphere + i];
+                if (live && !slow) {
+                    if (COUNT) ctr->prims++;
+                    const cuint4_p r = as_uniform(prims + unit);
+                    const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
+                    if (patch_prefilter(ray.o, pinv, R, mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)),
+                                        mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y)),
+                                        mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x)),
+                                        mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w)), tcs))
+                        defer_prim(unit | PM_DEFER_PATCH);
+                }
+            }
+        }
         // ---- exact round: the queued triangles, in the order they were met, minus the certain hits whose t bracket starts
         // beyond the final culling distance (they lie behind another certain hit); compacted first so that the wave makes
         // as many trips as its busiest lane has survivors
