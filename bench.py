@@ -78,8 +78,10 @@ def pmc_fields(kernel_regex, tag):
     if "valu_issue_frac" in v:
         out["issue"] = {"bound": "valu_issue", "frac": v["valu_issue_frac"], "active_lane_frac": v.get("active_lane_frac"),
                         "wait_frac": v.get("wait_frac"), "l2_hit_rate": v.get("l2_hit_rate"),
+                        "frac_with_scalar": v.get("issue_frac_with_scalar"), "scalar_per_vector_inst": v.get("scalar_per_vector_inst"),
                         "definition": "SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); lanes = "
-                                      "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64", "source": src}
+                                      "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64; frac_with_scalar adds SQ_INSTS_SALU "
+                                      "at one cycle each", "source": src}
     return out
 
 

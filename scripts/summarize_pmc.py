@@ -11,6 +11,9 @@ over them), and derived figures:
   l2_hit_rate                               TCC_HIT / (TCC_HIT + TCC_MISS)
   valu_issue_frac                           SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): a wave64 VALU
                                             instruction occupies its 32-lane-per-cycle SIMD for 2 cycles
+  issue_frac_with_scalar                    (SQ_INSTS_VALU x 2 + SQ_INSTS_SALU) / the same cycles: the scalar instructions of the
+                                            exec-mask bookkeeping counted at one issue cycle each (the flat sweep responded
+                                            linearly to instructions removed at 0.8 of this figure)
   active_lane_frac                          SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64 (calibrated: kernels that run full
                                             waves - raygen, accumulate - read 1.00)
   wait_frac                                 SQ_WAIT_ANY / SQ_WAVE_CYCLES
@@ -54,6 +57,10 @@ def main(paths):
             d["l2_hit_rate"] = m["TCC_HIT_sum"] / max(1.0, m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
         if "SQ_INSTS_VALU" in m and m.get("GRBM_GUI_ACTIVE", 0) > 0:
             d["valu_issue_frac"] = m["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * m["GRBM_GUI_ACTIVE"] / N_XCD)
+        if "SQ_INSTS_VALU" in m and "SQ_INSTS_SALU" in m and m.get("GRBM_GUI_ACTIVE", 0) > 0:
+            # scalar instructions counted at one issue cycle each beside the vector ones
+            d["issue_frac_with_scalar"] = (m["SQ_INSTS_VALU"] * 2.0 + m["SQ_INSTS_SALU"]) / (N_SIMD * m["GRBM_GUI_ACTIVE"] / N_XCD)
+            d["scalar_per_vector_inst"] = m["SQ_INSTS_SALU"] / max(1.0, m["SQ_INSTS_VALU"])
         if m.get("SQ_ACTIVE_INST_VALU", 0) > 0 and "SQ_THREAD_CYCLES_VALU" in m:
             d["active_lane_frac"] = m["SQ_THREAD_CYCLES_VALU"] / m["SQ_ACTIVE_INST_VALU"] / 64.0
         if m.get("SQ_WAVE_CYCLES", 0) > 0 and "SQ_WAIT_ANY" in m:
