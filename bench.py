@@ -121,7 +121,16 @@ def _oracle():
 
 
 def cpu_threads():
-    return min(16, len(os.sched_getaffinity(0)))
+    """every core this process may run on; where the box exports its CPU share (OMP_NUM_THREADS: 16 per GPU on the pool's
+    boxes, whose affinity mask shows the whole machine) that share bounds it"""
+    n = len(os.sched_getaffinity(0))
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    return max(1, min(n, int(share))) if share.isdigit() and int(share) > 0 else n
+
+
+def cpu_note():
+    return (f"nproc {os.cpu_count()}, affinity {len(os.sched_getaffinity(0))}, OMP_NUM_THREADS "
+            f"{os.environ.get('OMP_NUM_THREADS', 'unset')} (the box's CPU share); oracle built -O3 -mavx2 -mfma -ffp-contract=off")
 
 
 def cpu_baseline_trace(pos, idx, rays_sample, threads):
@@ -136,7 +145,7 @@ def cpu_baseline_trace(pos, idx, rays_sample, threads):
     t0 = time.time()
     hits, ctr = sc.intersect(rays_sample, nthreads=threads)
     dt = time.time() - t0
-    return {"value": len(rays_sample) / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+    return {"value": len(rays_sample) / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "host": cpu_note(),
             "sample": f"first {len(rays_sample)} primary rays of the same batch, closest hit; "
                       f"binary-BVH build {build_s:.1f}s not included",
             "nodes_per_ray": ctr["nodes_visited"] / len(rays_sample), "prims_per_ray": ctr["prims_tested"] / len(rays_sample)}
@@ -160,7 +169,7 @@ def cpu_baseline_path(pm, sd, spp, max_depth, threads, seconds, integrator=None,
         n += oren.render(p, threads)["samples"]
         s += 1
     dt = time.time() - t0
-    return {"value": n / dt, "unit": "samples/s", "cores": threads, "kind": "port",
+    return {"value": n / dt, "unit": "samples/s", "cores": threads, "kind": "port", "host": cpu_note(),
             "sample": f"rows {band[1]}..{band[3]} of the same {x1 - x0}x{y1 - y0} image, sample indices 0..{s} "
                       f"({n} path samples, {dt:.1f} s; reference-layout binary BVH built in {build_s:.1f} s, not included)"}
 
@@ -469,6 +478,107 @@ def sub(out, keys=("value", "unit", "ms_per_step", "roofline", "cpu_baseline")):
     return d
 
 
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def _roof_short(r):
+    """the roofline object of the contract, without the per-kernel tables"""
+    if not r:
+        return None
+    o = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "kernel_ms",
+                  "launches_per_step", "bytes_per_launch", "bytes_per_ray", "demand_GBps"))
+    if "issue" in r:
+        o["issue"] = _pick(r["issue"], ("bound", "frac", "active_lane_frac", "wait_frac", "frac_with_scalar"))
+    for k, v in list(o.items()):
+        if isinstance(v, float):
+            o[k] = float(f"{v:.5g}")
+    if "issue" in o:
+        o["issue"] = {k: (float(f"{v:.4g}") if isinstance(v, float) else v) for k, v in o["issue"].items()}
+    return o
+
+
+def _cpu_short(c):
+    if not c:
+        return None
+    o = _pick(c, ("value", "unit", "cores", "kind"))
+    o["value"] = float(f"{o['value']:.5g}")
+    o["sample"] = c.get("sample", "")[:160]
+    return o
+
+
+def _leg_short(leg):
+    o = {"value": float(f"{leg['value']:.6g}"), "unit": leg["unit"], "workload": leg.get("workload", "")[:110]}
+    if "ms_per_step" in leg:
+        o["ms_per_step"] = float(f"{leg['ms_per_step']:.5g}")
+    r = _roof_short(leg.get("roofline"))
+    if r:
+        o["roofline"] = _pick(r, ("bound", "achieved", "frac", "traffic", "kernel", "kernel_ms", "launches_per_step", "bytes_per_launch"))
+        if "issue" in r:
+            o["roofline"]["issue"] = _pick(r["issue"], ("frac", "active_lane_frac"))
+    if leg.get("cpu_baseline"):
+        o["cpu_baseline"] = _pick(_cpu_short(leg["cpu_baseline"]), ("value", "unit", "cores", "kind"))
+    return o
+
+
+HEADLINE_MAX = 3600   # bytes: the driver keeps only the tail of stdout (round 2's 22 KB line came back as parsed = null)
+
+
+def headline(full, full_path):
+    """The ONE line of the contract: the bench keys, `roofline` and `cpu_baseline` of the headline workload and the short
+    form of every other leg.  Everything else (per-kernel tables, queue counts, generator notes) lives in `full_path`."""
+    h = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                     "vs_baseline", "dtype", "data"))
+    h["value"] = float(f"{h['value']:.7g}")
+    h["ms_per_step"] = float(f"{h['ms_per_step']:.6g}")
+    cfg = full.get("config", {})
+    h["config"] = {"workload": cfg.get("workload", "")[:420]}
+    for k in ("integrator", "traversal", "merge", "samples_per_gpu", "rays_per_gpu", "passes", "bvh_build"):
+        if k in cfg:
+            h["config"][k] = cfg[k]
+    h["roofline"] = _roof_short(full.get("roofline"))
+    h["cpu_baseline"] = _cpu_short(full.get("cpu_baseline"))
+    for key in ("c2_point_light", "closest_hit", "c4_path", "c4_strong", "c5_path", "patch_mesh"):
+        if key in full:
+            h[key] = _leg_short(full[key])
+    ch = full.get("closest_hit", {})
+    for key in ("shadow_any_hit", "incoherent_closest_hit"):
+        if key in ch:
+            h["closest_hit"][key] = {"value": float(f"{ch[key]['value']:.6g}"), "unit": "Mrays/s"}
+    h["full"] = full_path
+    line = json.dumps(h, separators=(",", ":"))
+    # never let the line outgrow the driver's tail: shed the optional legs' text first, then the legs
+    for key in ("patch_mesh", "c5_path", "c4_strong", "c4_path", "c2_point_light", "closest_hit"):
+        if len(line) <= HEADLINE_MAX:
+            break
+        if key in h:
+            h[key].pop("workload", None)
+            if h[key].get("cpu_baseline"):
+                h[key]["cpu_baseline"].pop("sample", None)
+            line = json.dumps(h, separators=(",", ":"))
+    for key in ("patch_mesh", "c5_path", "c4_strong", "c4_path", "c2_point_light"):
+        if len(line) <= HEADLINE_MAX:
+            break
+        if h.pop(key, None) is not None:
+            line = json.dumps(h, separators=(",", ":"))
+    return line
+
+
+def emit(full):
+    """full record -> gpurun_out/bench_full.json (+ stderr); compact headline -> the LAST line of stdout"""
+    full_rel = os.path.join("gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, full_rel), "w") as f:
+            json.dump(full, f, indent=1)
+    except OSError as e:
+        note(f"could not write {full_rel}: {e}")
+        full_rel = "stderr"
+    print("[bench-full] " + json.dumps(full), file=sys.stderr, flush=True)
+    sys.stderr.flush()
+    print(headline(full, full_rel), flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -523,7 +633,7 @@ def main():
                 del integ5, sd5
                 out["c5_path"] = sub(c5)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
