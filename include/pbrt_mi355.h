@@ -32,6 +32,14 @@ extern "C" {
 
 #define PM_MISS 0xFFFFFFFFu
 
+/* ---- ABI handshake ---------------------------------------------------------------------------
+ * Every entry point that reads or writes one of the structs below takes the caller's sizeof() of that struct as
+ * `struct_bytes`; a caller compiled against another revision of this header gets PM_ERR_INVALID ("struct size mismatch")
+ * instead of the library reading past its array.  (Round 2: a C++ harness built before PmLight / PmMaterial grew ran
+ * against the rebuilt library and died of SIGSEGV inside pm_set_lights.)  PM_ABI_VERSION is bumped whenever a struct, an
+ * enum value or a signature changes; pm_abi_version() returns the library's. */
+#define PM_ABI_VERSION 3u
+
 typedef struct pm_ctx pm_ctx;
 
 /* core/ray.rs:7-14 (Ray{o,dir,time}; the medium pointer is not carried) + the t_max argument of
@@ -81,6 +89,7 @@ typedef struct PmCounters {
 /* device_id >= 0: a GPU context.  device_id == -1: host-only context (geometry, pm_build_accel and the
  * buffer getters work; every call that would launch a kernel returns PM_ERR_INVALID) — used to check the
  * tree on machines without a GPU. */
+uint32_t pm_abi_version(void);            /* == PM_ABI_VERSION of the header the library was built from */
 int pm_create(int device_id, pm_ctx** out);
 void pm_destroy(pm_ctx* ctx);
 const char* pm_last_error(pm_ctx* ctx);   /* valid until the next call on ctx */
@@ -88,7 +97,7 @@ const char* pm_last_error(pm_ctx* ctx);   /* valid until the next call on ctx */
 /* ---- scene geometry: replaces Vec<Arc<PrimitiveEnum>> handed to BVHAggregate::new
  * (primitives/aggregates.rs:25-47).  Primitive ids are assigned in insertion order across calls;
  * *first_prim_id receives the id of the first primitive added by the call. */
-int pm_add_spheres(pm_ctx* ctx, const PmSphere* spheres, uint32_t n, uint32_t* first_prim_id);
+int pm_add_spheres(pm_ctx* ctx, const PmSphere* spheres, uint32_t n, uint32_t* first_prim_id, uint32_t struct_bytes /* sizeof(PmSphere) */);
 /* shapes/bilinear_patch.rs:630-685 BilinearPatchMesh::new — positions already in render space,
  * 4 indices per patch in (p00,p10,p01,p11) order.  normals_or_null: one shading normal per vertex (n_vert x 3), already in
  * render space and already negated for reverse_orientation, as BilinearPatchMesh::new leaves them (bilinear_patch.rs:660-671;
@@ -113,7 +122,7 @@ int pm_clear_geometry(pm_ctx* ctx);
 /* BVHAggregate::new (primitives/aggregates.rs:25-47): builds the wide BVH (on the host, or on the device for
  * PM_SPLIT_HLBVH) and uploads it.  max_prims_in_node is an upper bound, as in the reference (whose SAH may stop earlier):
  * wide leaves hold at most 4 primitives, and triangle leaves always hold one (measured faster on 64-lane waves). */
-int pm_build_accel(pm_ctx* ctx, int split_method, int max_prims_in_node, PmAccelInfo* info_or_null);
+int pm_build_accel(pm_ctx* ctx, int split_method, int max_prims_in_node, PmAccelInfo* info_or_null, uint32_t struct_bytes /* sizeof(PmAccelInfo) */);
 
 /* ---- batched Primitive::intersect / intersect_p --------------------------------------------- */
 /* BVHAggregate::intersect (primitives/aggregates.rs:537-600), n rays -> n hits (closest hit). */
@@ -121,10 +130,12 @@ int pm_trace_closest(pm_ctx* ctx, const PmRay* rays, uint64_t n, PmHit* out);
 /* BVHAggregate::intersect_p (primitives/aggregates.rs:602-655), n rays -> n bytes (1 = occluded). */
 int pm_trace_any(pm_ctx* ctx, const PmRay* rays, uint64_t n, uint8_t* out);
 
-/* NO COUNTERPART IN THE REFERENCE.  pm_trace_closest for callers that cannot allocate device memory: code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels and bit-identical results, but it calls no
- * hipMalloc / hipFree or allocating library routine: the work counters and the deferred-primitive / slow-ray lists of the
- * kernels live in a file-scope device array of the library (15.8 MB per GPU, held until the process ends).  Limits: at most
+/* NO COUNTERPART IN THE REFERENCE.  pm_trace_closest for callers that cannot allocate device memory: harnesses that forbid
+ * hipMalloc once set-up is over, processes on a device whose memory is spoken for.  Same kernels and bit-identical results,
+ * but it calls no hipMalloc / hipFree or allocating library routine: the work counters and the deferred-primitive / slow-ray
+ * lists of the kernels live in a file-scope device array of the library (15.8 MB per GPU, held until the process ends).
+ * It is a BLOCKING call like pm_trace_closest (own stream, stream synchronise, overflow word read back, event timing), so it
+ * cannot be captured into a HIP graph.  Limits: at most
  * PM_NOALLOC_MAX_RAYS rays per call (more -> PM_ERR_INVALID); rays and out must be DEVICE pointers (else PM_ERR_INVALID).
  * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (from two contexts or threads) race. */
 #define PM_NOALLOC_MAX_RAYS (1u << 18)
@@ -133,7 +144,7 @@ int pm_trace_closest_noalloc(pm_ctx* ctx, const PmRay* d_rays, uint64_t n, PmHit
 /* ---- measurement ---------------------------------------------------------------------------- */
 int pm_set_counting(pm_ctx* ctx, int enabled);      /* counting kernels are slower; off by default */
 int pm_reset_counters(pm_ctx* ctx);
-int pm_get_counters(pm_ctx* ctx, PmCounters* out);
+int pm_get_counters(pm_ctx* ctx, PmCounters* out, uint32_t struct_bytes /* sizeof(PmCounters) */);
 /* device time (HIP events on the library's stream) of the kernels launched by the last trace/render call */
 int pm_last_kernel_ms(pm_ctx* ctx, float* ms);
 /* copies of the device-layout buffers, so a CPU checker can walk the very same tree
@@ -244,17 +255,18 @@ typedef struct PmRenderStats {
     uint64_t exact_tests, fallback_walks;   /* both ray kinds together */
 } PmRenderStats;
 
-int pm_set_materials(pm_ctx* ctx, const PmMaterial* mats, uint32_t n);
+int pm_set_materials(pm_ctx* ctx, const PmMaterial* mats, uint32_t n, uint32_t struct_bytes /* sizeof(PmMaterial) */);
 int pm_set_prim_materials(pm_ctx* ctx, const uint32_t* material_id_per_prim, uint32_t n);
-int pm_set_lights(pm_ctx* ctx, const PmLight* lights, uint32_t n);
-int pm_set_medium(pm_ctx* ctx, const PmMedium* medium_or_null);   /* NULL removes the medium */
-int pm_set_camera(pm_ctx* ctx, const PmCamera* cam);
-int pm_set_film(pm_ctx* ctx, const PmFilm* film);           /* (re)allocates and clears the film */
+int pm_set_lights(pm_ctx* ctx, const PmLight* lights, uint32_t n, uint32_t struct_bytes /* sizeof(PmLight) */);
+/* NULL removes the medium.  A rejected medium (negative / NaN coefficient) leaves the previous state untouched. */
+int pm_set_medium(pm_ctx* ctx, const PmMedium* medium_or_null, uint32_t struct_bytes /* sizeof(PmMedium) */);
+int pm_set_camera(pm_ctx* ctx, const PmCamera* cam, uint32_t struct_bytes /* sizeof(PmCamera) */);
+int pm_set_film(pm_ctx* ctx, const PmFilm* film, uint32_t struct_bytes /* sizeof(PmFilm) */);   /* (re)allocates and clears the film */
 /* Integrate::render() restricted to a pixel/sample window; accumulates into the film in sample-index order.
  * The window is rendered in passes of at most 2^26 paths (about 200 bytes of device memory per path, allocated on first
  * use and kept; never more than half of what is free on the device; PBRT_MI355_PASS_PATHS lowers it).  The film does not
  * depend on how the window is cut into passes. */
-int pm_render(pm_ctx* ctx, const PmRenderParams* params);
+int pm_render(pm_ctx* ctx, const PmRenderParams* params, uint32_t struct_bytes /* sizeof(PmRenderParams) */);
 int pm_film_clear(pm_ctx* ctx);
 /* RGBPixel{rgb_sum[3], weight_sum} as 4 doubles per pixel, row-major over pixel_bounds; host or device pointer */
 int pm_film_read(pm_ctx* ctx, double* rgbw);
@@ -262,13 +274,14 @@ int pm_film_read(pm_ctx* ctx, double* rgbw);
 int pm_film_add(pm_ctx* ctx, const double* rgbw);
 /* RGBFilm::get_pixel_rgb for every pixel (camera/film.rs:261-279): 3 floats per pixel */
 int pm_film_image(pm_ctx* ctx, float* rgb);
-int pm_get_render_stats(pm_ctx* ctx, PmRenderStats* out);
+int pm_get_render_stats(pm_ctx* ctx, PmRenderStats* out, uint32_t struct_bytes /* sizeof(PmRenderStats) */);
 /* queue occupancy of the last pm_render: entries of the closest-hit queue and of the shadow queue at bounce 0 .. max_depth
  * (summed over passes); *n_bounces receives max_depth + 1, at most cap entries are written to each array (either may be NULL) */
 int pm_get_queue_counts(pm_ctx* ctx, uint64_t* closest, uint64_t* shadow, uint32_t cap, uint32_t* n_bounces);
 /* test hook: unweighted radiance L[4] + lambda[4] + pdf[4] + filter weight of ONE (pixel, sample), recomputed
  * on the device with the same kernels (13 floats) */
-int pm_debug_sample(pm_ctx* ctx, const PmRenderParams* params, int32_t px, int32_t py, int32_t sample_index, float* out13);
+int pm_debug_sample(pm_ctx* ctx, const PmRenderParams* params, int32_t px, int32_t py, int32_t sample_index, float* out13,
+                    uint32_t struct_bytes /* sizeof(PmRenderParams) */);
 
 /* test hook: the first n uniforms that IndependentSampler::get_1d returns after start_pixel_sample((px,py), sample_index,
  * dimension) with this seed (sampling/sampler.rs:104-124, util/rng.rs:15-50), drawn by the device's PCG32 / murmur3 code */
@@ -280,6 +293,10 @@ int pm_debug_uniforms(pm_ctx* ctx, int32_t px, int32_t py, uint32_t seed, uint64
  * evaluates them in f64 and rounds once (csrc/pm_crmath.hpp).  which: 0 atanh (|x| < 1), 1 cosh (|x| <= 2.2), 2 exp, 3 log,
  * 4 / 5 sin / cos of an azimuth in [0, 2 pi], 6 / 7 sin / cos of the concentric-disk angle in [-pi/4, 3 pi/4] */
 int pm_debug_math(pm_ctx* ctx, int32_t which, const float* x, int32_t n, float* out);
+
+/* test hook (host state only, works on a host-only context): out4 = { medium set ? 1 : 0, g, sigma_a[0], sigma_s[0] } of the
+ * medium the next render would use - shows that a rejected pm_set_medium left the previous state in place */
+int pm_debug_medium_state(pm_ctx* ctx, float* out4);
 
 #ifdef __cplusplus
 }

@@ -230,7 +230,7 @@ public:
                     std::memcpy(ps.render_from_object, s->render_from_object.m.data(), 64);
                     std::memcpy(ps.object_from_render, s->render_from_object.m_inv.data(), 64);
                     ps.reverse_orientation = s->reverse_orientation ? 1u : 0u;
-                    check(pm_add_spheres(ctx_, &ps, 1, &first));
+                    check(pm_add_spheres(ctx_, &ps, 1, &first, (uint32_t)sizeof(PmSphere)));
                 } else if (const auto* m = std::get_if<BilinearPatchMesh>(&p)) {
                     check(pm_add_patch_mesh(ctx_, m->positions.data(), (uint32_t)(m->positions.size() / 3), m->indices.data(),
                                             (uint32_t)(m->indices.size() / 4), m->normals.empty() ? nullptr : m->normals.data(),
@@ -241,7 +241,7 @@ public:
                                                (uint32_t)(t.indices.size() / 3), &first));
                 }
             }
-            check(pm_build_accel(ctx_, split_method, max_prims_in_node, &info));
+            check(pm_build_accel(ctx_, split_method, max_prims_in_node, &info, (uint32_t)sizeof(PmAccelInfo)));
         } catch (...) { pm_destroy(ctx_); ctx_ = nullptr; throw; }
     }
     ~GpuAggregate() { if (ctx_) pm_destroy(ctx_); }
@@ -275,7 +275,7 @@ public:
             mats[i].u_roughness = sd_.materials[i].u_roughness; mats[i].v_roughness = sd_.materials[i].v_roughness;
             mats[i].remap_roughness = sd_.materials[i].remap_roughness ? 1 : 0;
         }
-        agg_.check(pm_set_materials(agg_.ctx(), mats.data(), (uint32_t)mats.size()));
+        agg_.check(pm_set_materials(agg_.ctx(), mats.data(), (uint32_t)mats.size(), (uint32_t)sizeof(PmMaterial)));
         agg_.check(pm_set_prim_materials(agg_.ctx(), sd_.prim_materials.data(), (uint32_t)sd_.prim_materials.size()));
         std::vector<PmLight> lights(sd_.lights.size());
         for (size_t i = 0; i < lights.size(); ++i) {
@@ -283,8 +283,8 @@ public:
             std::memcpy(lights[i].render_from_light, sd_.lights[i].render_from_light.m.data(), 64);
             lights[i].spectrum = sd_.lights[i].spectrum.data();
         }
-        agg_.check(pm_set_lights(agg_.ctx(), lights.data(), (uint32_t)lights.size()));
-        agg_.check(pm_set_camera(agg_.ctx(), &sd_.camera));
+        agg_.check(pm_set_lights(agg_.ctx(), lights.data(), (uint32_t)lights.size(), (uint32_t)sizeof(PmLight)));
+        agg_.check(pm_set_camera(agg_.ctx(), &sd_.camera, (uint32_t)sizeof(PmCamera)));
         PmFilm f{};
         std::memcpy(f.full_resolution, sd_.film.full_resolution, 8); std::memcpy(f.pixel_bounds, sd_.film.pixel_bounds, 16);
         f.max_component_value = sd_.film.max_component_value; f.imaging_ratio = sd_.film.imaging_ratio;
@@ -292,7 +292,7 @@ public:
         f.sensor_rgb_bar = sd_.film.sensor.data();
         f.filter_kind = sd_.film.filter_kind; f.filter_radius[0] = sd_.film.filter_radius[0]; f.filter_radius[1] = sd_.film.filter_radius[1];
         f.filter_nx = sd_.film.filter_nx; f.filter_ny = sd_.film.filter_ny; f.filter_vals = sd_.film.filter_vals.data();
-        agg_.check(pm_set_film(agg_.ctx(), &f));
+        agg_.check(pm_set_film(agg_.ctx(), &f, (uint32_t)sizeof(PmFilm)));
         params.integrator = integrator; params.max_depth = max_depth; params.sample_lights = sample_lights; params.sample_bsdf = sample_bsdf;
         params.spp = spp; params.seed = seed;
         std::memcpy(params.window, sd_.film.pixel_bounds, 16);
@@ -301,7 +301,7 @@ public:
     int width() const { return sd_.film.pixel_bounds[2] - sd_.film.pixel_bounds[0]; }
     int height() const { return sd_.film.pixel_bounds[3] - sd_.film.pixel_bounds[1]; }
     // Integrate::render(): the whole image, or params.window / params.s0..s1 of it
-    PmRenderStats render() { agg_.check(pm_render(agg_.ctx(), &params)); PmRenderStats st{}; agg_.check(pm_get_render_stats(agg_.ctx(), &st)); return st; }
+    PmRenderStats render() { agg_.check(pm_render(agg_.ctx(), &params, (uint32_t)sizeof(PmRenderParams))); PmRenderStats st{}; agg_.check(pm_get_render_stats(agg_.ctx(), &st, (uint32_t)sizeof(PmRenderStats))); return st; }
     // the same in the reference's waves of sample indices (integrators/base.rs:85-127: [0,1) [1,2) [2,4) ... doubling up to 64);
     // after each wave on_wave(wave_start, wave_end) may read a progressive image.  Final film bit-identical to render().
     template <class F>
@@ -312,13 +312,13 @@ public:
         while (wave_start < spp) {
             PmRenderParams p = params;
             p.s0 = wave_start; p.s1 = wave_end;
-            agg_.check(pm_render(agg_.ctx(), &p));
+            agg_.check(pm_render(agg_.ctx(), &p, (uint32_t)sizeof(PmRenderParams)));
             on_wave(wave_start, wave_end);
             wave_start = wave_end;
             wave_end = std::min(spp, wave_end + next_wave_size);
             next_wave_size = std::min(2 * next_wave_size, 64);
         }
-        agg_.check(pm_get_render_stats(agg_.ctx(), &st));
+        agg_.check(pm_get_render_stats(agg_.ctx(), &st, (uint32_t)sizeof(PmRenderStats)));
         return st;
     }
     void clear() { agg_.check(pm_film_clear(agg_.ctx())); }

@@ -131,13 +131,13 @@ struct WideWalker {
                     rmin(rmin(p00.z, p10.z), rmin(p01.z, p11.z)));
         const V3 hi(rmax(rmax(p00.x, p10.x), rmax(p01.x, p11.x)), rmax(rmax(p00.y, p10.y), rmax(p01.y, p11.y)),
                     rmax(rmax(p00.z, p10.z), rmax(p01.z, p11.z)));
-        const float pad = 1e-5f * rmax(rmax(maxabs(lo), maxabs(hi)), R);
+        const float pad = 1e-4f * rmax(rmax(maxabs(lo), maxabs(hi)), R);
         const float ax = ((lo.x - pad) - ro.x) * inv.x, bx = ((hi.x + pad) - ro.x) * inv.x;
         const float ay = ((lo.y - pad) - ro.y) * inv.y, by = ((hi.y + pad) - ro.y) * inv.y;
         const float az = ((lo.z - pad) - ro.z) * inv.z, bz = ((hi.z + pad) - ro.z) * inv.z;
         const float tn = rmax(rmax(rmin(ax, bx), rmin(ay, by)), rmax(rmin(az, bz), 0.0f));
         const float tf = rmin(rmin(rmax(ax, bx), rmax(ay, by)), rmin(rmax(az, bz), tcull));
-        return tn <= tf * 1.00001f;
+        return tn <= tf * 1.0001f;
     }
     static bool sphere_prefilter(V3 ro, V3 rd, float R, float D, const float* m, float radius, float m_norm, float t_norm, float tcull) {
         const float EPS = 4.76837158203125e-07f;

@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpbrt_mi355.so")
 
 PM_OK = 0
+PM_ERR_INVALID, PM_ERR_HIP, PM_ERR_NO_ACCEL, PM_ERR_UNSUPPORTED, PM_ERR_STACK_OVERFLOW = 1, 2, 3, 4, 5
+PM_ABI_VERSION = 3
 PM_MISS = 0xFFFFFFFF
 PM_NOALLOC_MAX_RAYS = 1 << 18
 PM_SPLIT_HLBVH, PM_SPLIT_SAH, PM_SPLIT_MIDDLE, PM_SPLIT_EQUAL_COUNTS = 0, 1, 2, 3
@@ -102,37 +104,39 @@ SYMBOLS = {
     "pm_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "pm_destroy": (None, [_P]),
     "pm_last_error": (C.c_char_p, [_P]),
-    "pm_add_spheres": (C.c_int, [_P, C.POINTER(PmSphere), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "pm_abi_version": (C.c_uint32, []),
+    "pm_add_spheres": (C.c_int, [_P, C.POINTER(PmSphere), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]),
     "pm_add_patch_mesh": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_int, C.c_int, C.POINTER(C.c_uint32)]),
     "pm_add_patch_mesh_uv": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_uint32)]),
     "pm_add_triangle_mesh": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     "pm_clear_geometry": (C.c_int, [_P]),
-    "pm_build_accel": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(PmAccelInfo)]),
+    "pm_build_accel": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(PmAccelInfo), C.c_uint32]),
     "pm_trace_closest": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "pm_trace_any": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "pm_trace_closest_noalloc": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "pm_set_counting": (C.c_int, [_P, C.c_int]),
     "pm_reset_counters": (C.c_int, [_P]),
-    "pm_get_counters": (C.c_int, [_P, C.POINTER(PmCounters)]),
+    "pm_get_counters": (C.c_int, [_P, C.POINTER(PmCounters), C.c_uint32]),
     "pm_last_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "pm_get_node_buffer": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "pm_get_prim_buffer": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
-    "pm_set_materials": (C.c_int, [_P, C.POINTER(PmMaterial), C.c_uint32]),
+    "pm_set_materials": (C.c_int, [_P, C.POINTER(PmMaterial), C.c_uint32, C.c_uint32]),
     "pm_set_prim_materials": (C.c_int, [_P, _P, C.c_uint32]),
-    "pm_set_lights": (C.c_int, [_P, C.POINTER(PmLight), C.c_uint32]),
-    "pm_set_medium": (C.c_int, [_P, C.POINTER(PmMedium)]),
-    "pm_set_camera": (C.c_int, [_P, C.POINTER(PmCamera)]),
-    "pm_set_film": (C.c_int, [_P, C.POINTER(PmFilm)]),
-    "pm_render": (C.c_int, [_P, C.POINTER(PmRenderParams)]),
+    "pm_set_lights": (C.c_int, [_P, C.POINTER(PmLight), C.c_uint32, C.c_uint32]),
+    "pm_set_medium": (C.c_int, [_P, C.POINTER(PmMedium), C.c_uint32]),
+    "pm_set_camera": (C.c_int, [_P, C.POINTER(PmCamera), C.c_uint32]),
+    "pm_set_film": (C.c_int, [_P, C.POINTER(PmFilm), C.c_uint32]),
+    "pm_render": (C.c_int, [_P, C.POINTER(PmRenderParams), C.c_uint32]),
     "pm_film_clear": (C.c_int, [_P]),
     "pm_film_read": (C.c_int, [_P, _P]),
     "pm_film_add": (C.c_int, [_P, _P]),
     "pm_film_image": (C.c_int, [_P, _P]),
-    "pm_get_render_stats": (C.c_int, [_P, C.POINTER(PmRenderStats)]),
+    "pm_get_render_stats": (C.c_int, [_P, C.POINTER(PmRenderStats), C.c_uint32]),
     "pm_get_queue_counts": (C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
-    "pm_debug_sample": (C.c_int, [_P, C.POINTER(PmRenderParams), C.c_int32, C.c_int32, C.c_int32, _P]),
+    "pm_debug_sample": (C.c_int, [_P, C.POINTER(PmRenderParams), C.c_int32, C.c_int32, C.c_int32, _P, C.c_uint32]),
     "pm_debug_uniforms": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32, _P]),
     "pm_debug_math": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P]),
+    "pm_debug_medium_state": (C.c_int, [_P, C.POINTER(C.c_float)]),
     # include/pbrt_mi355_host.h
     "pmh_mat4_inverse": (C.c_int, [_P, _P]),
     "pmh_mat4_mul": (None, [_P, _P, _P]),

@@ -96,7 +96,7 @@ class GpuAggregate:
                 s.render_from_object[:] = p.render_from_object.reshape(-1).tolist()
                 s.object_from_render[:] = p.object_from_render.reshape(-1).tolist()
                 s.reverse_orientation = 1 if p.reverse_orientation else 0
-                self._check(self._lib.pm_add_spheres(self._h, C.byref(s), 1, C.byref(first)))
+                self._check(self._lib.pm_add_spheres(self._h, C.byref(s), 1, C.byref(first), C.sizeof(s)))
             elif isinstance(p, BilinearPatchMesh):
                 self._check(self._lib.pm_add_patch_mesh_uv(
                     self._h, p.positions.ctypes.data, len(p.positions), p.indices.ctypes.data, len(p.indices),
@@ -110,7 +110,7 @@ class GpuAggregate:
                 raise TypeError(f"unknown primitive {type(p)}")
             self.first_prim_id.append(first.value)
         self.info = PmAccelInfo()
-        self._check(self._lib.pm_build_accel(self._h, split_method, max_prims_in_node, C.byref(self.info)))
+        self._check(self._lib.pm_build_accel(self._h, split_method, max_prims_in_node, C.byref(self.info), C.sizeof(self.info)))
 
     # -- Primitive trait -----------------------------------------------------------------------
     def bounds(self):
@@ -154,7 +154,7 @@ class GpuAggregate:
 
     def counters(self):
         c = PmCounters()
-        self._check(self._lib.pm_get_counters(self._h, C.byref(c)))
+        self._check(self._lib.pm_get_counters(self._h, C.byref(c), C.sizeof(c)))
         return {"rays": c.rays, "nodes_visited": c.nodes_visited, "prims_tested": c.prims_tested,
                 "stack_overflows": c.stack_overflows, "exact_tests": c.exact_tests, "fallback_walks": c.fallback_walks}
 

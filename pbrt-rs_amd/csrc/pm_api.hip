@@ -1,6 +1,7 @@
 // C ABI of libpbrt_mi355.so (include/pbrt_mi355.h): context, geometry upload, wide-BVH build,
 // batched closest-hit / any-hit kernels.  gfx950 only.
 #include <cstdlib>
+#include <mutex>
 
 #include "pm_ctx.h"
 #include "pm_device.hpp"
@@ -21,6 +22,7 @@
 static __device__ __align__(256) unsigned char scratch[PM_NA_SCRATCH_BYTES];
 #define PM_MAX_DEVICES 64
 static unsigned char* g_scratch_ptr[PM_MAX_DEVICES];     // per device: each GPU has its own copy at its own address
+static std::mutex g_scratch_mutex;                       // contexts may be created from several threads at once
 static_assert(3 * PM_WORK_SLOTS * sizeof(uint32_t) <= PM_NA_OFF_COUNTERS, "work counters overlap the error counters");
 
 // ------------------------------------------------------------------------------------------ kernels
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_fix_kernel(PmFlatScene fs, 
 int pm_gpu_build_tris(pm_ctx* c, int max_leaf, std::string& err);   // pm_gpu_build.hip
 
 // ------------------------------------------------------------------------------------------ lifetime
+extern "C" uint32_t pm_abi_version(void) { return PM_ABI_VERSION; }
 extern "C" int pm_create(int device_id, pm_ctx** out) {
     if (!out) return PM_ERR_INVALID;
     *out = nullptr;
@@ -164,6 +167,7 @@ extern "C" int pm_create(int device_id, pm_ctx** out) {
     }
     // device address of this GPU's copy of `scratch` (hipSetDevice(device_id) above made it current)
     if (device_id < PM_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
         if (!g_scratch_ptr[device_id]) {
             unsigned char* ptr = nullptr;
             if (hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) { pm_destroy(c); return PM_ERR_HIP; }
@@ -207,8 +211,9 @@ static pm::Box box_of_points(const float (*p)[3], int n) {
 }
 static float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-extern "C" int pm_add_spheres(pm_ctx* c, const PmSphere* s, uint32_t n, uint32_t* first) {
+extern "C" int pm_add_spheres(pm_ctx* c, const PmSphere* s, uint32_t n, uint32_t* first, uint32_t struct_bytes) {
     if (!c || (!s && n)) return fail(c, PM_ERR_INVALID, "pm_add_spheres: null argument");
+    PM_ABI_CHECK(c, PmSphere, struct_bytes, "pm_add_spheres");
     for (uint32_t i = 0; i < n; ++i) {
         const float* ofr = s[i].object_from_render;
         const float* rfo = s[i].render_from_object;
@@ -301,8 +306,9 @@ extern "C" int pm_clear_geometry(pm_ctx* c) {
     return PM_OK;
 }
 
-extern "C" int pm_build_accel(pm_ctx* c, int split_method, int max_prims_in_node, PmAccelInfo* info) {
+extern "C" int pm_build_accel(pm_ctx* c, int split_method, int max_prims_in_node, PmAccelInfo* info, uint32_t struct_bytes) {
     if (!c) return PM_ERR_INVALID;
+    if (info) PM_ABI_CHECK(c, PmAccelInfo, struct_bytes, "pm_build_accel");
     if (split_method < PM_SPLIT_HLBVH || split_method > PM_SPLIT_EQUAL_COUNTS)
         return fail(c, PM_ERR_INVALID, "pm_build_accel: unknown split method");
     if (c->device >= 0) HIPCHK(c, hipSetDevice(c->device));
@@ -463,7 +469,9 @@ extern "C" int pm_trace_any(pm_ctx* c, const PmRay* rays, uint64_t n, uint8_t* o
 }
 
 // pm_trace_closest for callers that cannot allocate: same kernels, same results, no hipMalloc / hipFree (nor any allocating
-// library routine) - everything the kernels need beyond rays and hits comes from this GPU's `scratch`.  Both buffers must be
+// library routine) - everything the kernels need beyond rays and hits comes from this GPU's `scratch`.  It is NOT capturable
+// into a HIP graph and it is a blocking call: like pm_trace_closest it launches on the context's own stream, waits for it,
+// reads the overflow word back and times the launch with events.  Both buffers must be
 // device memory (a host buffer would need staging, i.e. an allocation).  Calls on one GPU share that GPU's scratch, which
 // keeps the last call's contents: the first 4 KB (work counters, error counters) are cleared here, the lists are rewritten
 // up to the counts the kernels themselves produce.  Calls that overlap on one GPU (two contexts, two threads) race.
@@ -508,8 +516,9 @@ extern "C" int pm_reset_counters(pm_ctx* c) {
     c->rays_counted = 0;
     return PM_OK;
 }
-extern "C" int pm_get_counters(pm_ctx* c, PmCounters* out) {
+extern "C" int pm_get_counters(pm_ctx* c, PmCounters* out, uint32_t struct_bytes) {
     if (!c || !out || c->device < 0) return PM_ERR_INVALID;
+    PM_ABI_CHECK(c, PmCounters, struct_bytes, "pm_get_counters");
     HIPCHK(c, hipSetDevice(c->device));
     unsigned long long v[8];
     HIPCHK(c, hipMemcpy(v, c->d_counters, sizeof(v), hipMemcpyDeviceToHost));

@@ -79,6 +79,14 @@ struct pm_ctx {
 void pm_render_state_destroy(pm_ctx* c);
 
 static inline int fail(pm_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+// ABI handshake (pbrt_mi355.h): the caller's sizeof(T) must be the library's
+#define PM_ABI_CHECK(c, T, bytes, fn)                                                                                          \
+    do {                                                                                                                       \
+        if ((bytes) != (uint32_t)sizeof(T))                                                                                    \
+            return fail(c, PM_ERR_INVALID, std::string(fn) + ": struct size mismatch for " #T " (caller " + std::to_string(bytes) + \
+                                               " bytes, library " + std::to_string(sizeof(T)) + ", ABI version " +              \
+                                               std::to_string(PM_ABI_VERSION) + "): the caller was built against another pbrt_mi355.h"); \
+    } while (0)
 #define HIPCHK(c, call)                                                                              \
     do {                                                                                             \
         hipError_t e_ = (call);                                                                      \

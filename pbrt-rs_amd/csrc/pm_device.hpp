@@ -351,13 +351,13 @@ PMD bool patch_prefilter(f3 ro, f3 inv, float R, f3 p00, f3 p10, f3 p01, f3 p11,
                       fminf(fminf(p00.z, p10.z), fminf(p01.z, p11.z)));
     const f3 hi = mk3(fmaxf(fmaxf(p00.x, p10.x), fmaxf(p01.x, p11.x)), fmaxf(fmaxf(p00.y, p10.y), fmaxf(p01.y, p11.y)),
                       fmaxf(fmaxf(p00.z, p10.z), fmaxf(p01.z, p11.z)));
-    const float pad = 1e-5f * fmaxf(fmaxf(maxc3(abs3(lo)), maxc3(abs3(hi))), R);
+    const float pad = 1e-4f * fmaxf(fmaxf(maxc3(abs3(lo)), maxc3(abs3(hi))), R);
     const float ax = ((lo.x - pad) - ro.x) * inv.x, bx = ((hi.x + pad) - ro.x) * inv.x;
     const float ay = ((lo.y - pad) - ro.y) * inv.y, by = ((hi.y + pad) - ro.y) * inv.y;
     const float az = ((lo.z - pad) - ro.z) * inv.z, bz = ((hi.z + pad) - ro.z) * inv.z;
     const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
     const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tcull));
-    return tn <= tf * 1.00001f;
+    return tn <= tf * 1.0001f;
 }
 
 // ---- float pre-filter for spheres: false = the exact (interval) test cannot accept this sphere with t <= tcull.
@@ -1206,7 +1206,10 @@ PMD void deferred_fix(FlatScene fs, const uint4* __restrict__ prims, const uint4
                       const uint32_t* __restrict__ defer_count, const uint32_t* __restrict__ slow_list,
                       const uint32_t* __restrict__ slow_count, uint32_t defer_cap, uint4* buf, TravCounters* ctr, FetchFn fetch,
                       LoadTFn load_t, CommitFn commit) {
-    const uint32_t n = *defer_count < defer_cap ? *defer_count : defer_cap;      // (an overflowing pass 1 has reported itself)
+    // An overflowing pass 1 has reported itself (the call returns PM_ERR_STACK_OVERFLOW, results invalid) and nothing was
+    // written for the reservations that did not fit - but the counter went on counting, so the entries between the last
+    // chunk that fitted and `cap` are whatever an earlier launch left there.  Such a list is not processed at all.
+    const uint32_t n = *defer_count <= defer_cap ? *defer_count : 0u;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     uint32_t cnt = 0;                                   // wave-uniform: valid entries waiting in buf
@@ -1246,7 +1249,7 @@ PMD void deferred_fix(FlatScene fs, const uint4* __restrict__ prims, const uint4
     }
     // ---- slow rays (flat sweep only): everything, exactly.  Same gathering, in the first 128 words of buf.
     if (slow_list == nullptr) return;
-    const uint32_t ns = *slow_count < defer_cap ? *slow_count : defer_cap;
+    const uint32_t ns = *slow_count <= defer_cap ? *slow_count : 0u;
     uint32_t* ibuf = reinterpret_cast<uint32_t*>(buf);
     cnt = 0;
     for (uint32_t base = wave * 64u; base < ns || cnt > 0u; base += n_waves * 64u) {

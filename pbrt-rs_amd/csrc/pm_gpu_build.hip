@@ -334,7 +334,13 @@ int pm_gpu_build_tris(pm_ctx* c, int max_leaf, std::string& err) {
         int levels = 1;
         while ((1ull << levels) <= n) ++levels;                 // levels 0 .. floor(log2(n))
         DevBuf table;
-        GBCHK(table.alloc((size_t)levels * n * sizeof(GBox)));
+        // levels * n * 24 bytes (12.6 GB at 21 M triangles): when the device cannot spare it - ranks sharing a card, a nearly
+        // full device - the scene goes to the host builder instead of failing (PM_ERR_UNSUPPORTED = "use the host build")
+        if (table.alloc((size_t)levels * n * sizeof(GBox)) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(st);
+            return PM_ERR_UNSUPPORTED;
+        }
         GBox* T = table.as<GBox>();
         hipLaunchKernelGGL(leafbox_kernel, dim3(grid_n), dim3(GB_BLOCK), 0, st, tris.as<pm::HostTri>(), vals2.as<uint32_t>(), (int)n, T);
         for (int k = 1; k < levels; ++k)

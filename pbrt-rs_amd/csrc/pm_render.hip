@@ -1014,27 +1014,27 @@ static RenderState* rs(pm_ctx* c) { if (!c->render) c->render = new RenderState(
 
 static bool spec_needs_table(int kind) { return kind == PM_SPEC_DENSE || kind == PM_SPEC_RGB_ILLUMINANT; }
 
-extern "C" int pm_set_materials(pm_ctx* c, const PmMaterial* m, uint32_t n) {
+extern "C" int pm_set_materials(pm_ctx* c, const PmMaterial* m, uint32_t n, uint32_t struct_bytes) {
     if (!c || (!m && n)) return fail(c, PM_ERR_INVALID, "pm_set_materials: null argument");
+    PM_ABI_CHECK(c, PmMaterial, struct_bytes, "pm_set_materials");
     RenderState* r = rs(c);
-    r->mats.assign(m, m + n); r->mat_tables.assign(n, {}); r->mat_tables2.assign(n, {});
-    for (uint32_t i = 0; i < n; ++i) {
+    for (uint32_t i = 0; i < n; ++i) {      // validate everything first: a rejected call leaves the previous materials in place
         if (m[i].type != PM_MAT_DIFFUSE && m[i].type != PM_MAT_DIELECTRIC) return fail(c, PM_ERR_INVALID, "pm_set_materials: unknown material type");
         if (m[i].spectrum.kind < PM_SPEC_CONSTANT || m[i].spectrum.kind > PM_SPEC_BLACKBODY) return fail(c, PM_ERR_INVALID, "pm_set_materials: unknown spectrum kind");
-        if (spec_needs_table(m[i].spectrum.kind)) {
-            if (!m[i].spectrum.table) return fail(c, PM_ERR_INVALID, "pm_set_materials: spectrum needs a 471-entry table");
-            r->mat_tables[i].assign(m[i].spectrum.table, m[i].spectrum.table + 471);
-        }
-        r->mats[i].spectrum.table = nullptr;
+        if (spec_needs_table(m[i].spectrum.kind) && !m[i].spectrum.table) return fail(c, PM_ERR_INVALID, "pm_set_materials: spectrum needs a 471-entry table");
         if (m[i].texture != PM_TEX_NONE && m[i].texture != PM_TEX_CHECKERBOARD) return fail(c, PM_ERR_INVALID, "pm_set_materials: unknown texture kind");
         if (m[i].texture != PM_TEX_NONE) {
             if (m[i].type != PM_MAT_DIFFUSE) return fail(c, PM_ERR_UNSUPPORTED, "pm_set_materials: textures are supported on diffuse materials only");
             if (m[i].spectrum2.kind < PM_SPEC_CONSTANT || m[i].spectrum2.kind > PM_SPEC_BLACKBODY) return fail(c, PM_ERR_INVALID, "pm_set_materials: unknown spectrum kind (spectrum2)");
-            if (spec_needs_table(m[i].spectrum2.kind)) {
-                if (!m[i].spectrum2.table) return fail(c, PM_ERR_INVALID, "pm_set_materials: spectrum2 needs a 471-entry table");
-                r->mat_tables2[i].assign(m[i].spectrum2.table, m[i].spectrum2.table + 471);
-            }
+            if (spec_needs_table(m[i].spectrum2.kind) && !m[i].spectrum2.table) return fail(c, PM_ERR_INVALID, "pm_set_materials: spectrum2 needs a 471-entry table");
         }
+    }
+    r->mats.assign(m, m + n); r->mat_tables.assign(n, {}); r->mat_tables2.assign(n, {});
+    for (uint32_t i = 0; i < n; ++i) {
+        if (spec_needs_table(m[i].spectrum.kind)) r->mat_tables[i].assign(m[i].spectrum.table, m[i].spectrum.table + 471);
+        r->mats[i].spectrum.table = nullptr;
+        if (m[i].texture != PM_TEX_NONE && spec_needs_table(m[i].spectrum2.kind))
+            r->mat_tables2[i].assign(m[i].spectrum2.table, m[i].spectrum2.table + 471);
         r->mats[i].spectrum2.table = nullptr;
     }
     r->scene_dirty = true;
@@ -1047,8 +1047,9 @@ extern "C" int pm_set_prim_materials(pm_ctx* c, const uint32_t* ids, uint32_t n)
     r->scene_dirty = true;
     return PM_OK;
 }
-extern "C" int pm_set_lights(pm_ctx* c, const PmLight* l, uint32_t n) {
+extern "C" int pm_set_lights(pm_ctx* c, const PmLight* l, uint32_t n, uint32_t struct_bytes) {
     if (!c || (!l && n)) return fail(c, PM_ERR_INVALID, "pm_set_lights: null argument");
+    PM_ABI_CHECK(c, PmLight, struct_bytes, "pm_set_lights");
     RenderState* r = rs(c);
     for (uint32_t i = 0; i < n; ++i) {
         if (l[i].type < PM_LIGHT_POINT || l[i].type > PM_LIGHT_DIFFUSE_AREA) return fail(c, PM_ERR_INVALID, "pm_set_lights: unknown light type");
@@ -1059,23 +1060,34 @@ extern "C" int pm_set_lights(pm_ctx* c, const PmLight* l, uint32_t n) {
     r->scene_dirty = true;
     return PM_OK;
 }
-extern "C" int pm_set_medium(pm_ctx* c, const PmMedium* m) {
+extern "C" int pm_set_medium(pm_ctx* c, const PmMedium* m, uint32_t struct_bytes) {
     if (!c) return PM_ERR_INVALID;
     RenderState* r = rs(c);
-    r->scene_dirty = true;
-    if (!m) { r->have_medium = false; return PM_OK; }
+    if (!m) { r->have_medium = false; r->scene_dirty = true; return PM_OK; }
+    PM_ABI_CHECK(c, PmMedium, struct_bytes, "pm_set_medium");
+    // everything is validated BEFORE the state is touched: a rejected medium leaves the previous one (or none) in place
     if (!m->sigma_a || !m->sigma_s) return fail(c, PM_ERR_INVALID, "pm_set_medium: sigma_a and sigma_s tables (471 floats each) are required");
     for (int k = 0; k < 3; ++k) if (!(m->bounds[k] < m->bounds[3 + k])) return fail(c, PM_ERR_INVALID, "pm_set_medium: empty bounds");
     if (!(std::fabs(m->g) < 1.0f)) return fail(c, PM_ERR_INVALID, "pm_set_medium: |g| must be < 1");
+    for (int k = 0; k < 471; ++k)
+        if (!(m->sigma_a[k] >= 0.0f) || !(m->sigma_s[k] >= 0.0f) || std::isinf(m->sigma_a[k]) || std::isinf(m->sigma_s[k]))
+            return fail(c, PM_ERR_INVALID, "pm_set_medium: negative, infinite or NaN coefficient");
     r->medium = *m; r->have_medium = true;
     r->med_sigma_a.assign(m->sigma_a, m->sigma_a + 471); r->med_sigma_s.assign(m->sigma_s, m->sigma_s + 471);
-    for (int k = 0; k < 471; ++k)
-        if (!(r->med_sigma_a[k] >= 0.0f) || !(r->med_sigma_s[k] >= 0.0f)) return fail(c, PM_ERR_INVALID, "pm_set_medium: negative coefficient");
     r->medium.sigma_a = nullptr; r->medium.sigma_s = nullptr;
+    r->scene_dirty = true;
     return PM_OK;
 }
-extern "C" int pm_set_camera(pm_ctx* c, const PmCamera* cam) {
+extern "C" int pm_debug_medium_state(pm_ctx* c, float* out4) {
+    if (!c || !out4) return fail(c, PM_ERR_INVALID, "pm_debug_medium_state: null argument");
+    RenderState* r = rs(c);
+    out4[0] = r->have_medium ? 1.0f : 0.0f; out4[1] = r->have_medium ? r->medium.g : 0.0f;
+    out4[2] = r->have_medium ? r->med_sigma_a[0] : 0.0f; out4[3] = r->have_medium ? r->med_sigma_s[0] : 0.0f;
+    return PM_OK;
+}
+extern "C" int pm_set_camera(pm_ctx* c, const PmCamera* cam, uint32_t struct_bytes) {
     if (!c || !cam) return fail(c, PM_ERR_INVALID, "pm_set_camera: null argument");
+    PM_ABI_CHECK(c, PmCamera, struct_bytes, "pm_set_camera");
     const float* m = cam->render_from_camera;
     if (!(m[12] == 0.f && m[13] == 0.f && m[14] == 0.f && m[15] == 1.f)) return fail(c, PM_ERR_UNSUPPORTED, "pm_set_camera: render_from_camera must be affine");
     RenderState* r = rs(c);
@@ -1095,8 +1107,9 @@ static float pc1d_build(const float* f, int n, float mn, float mx, std::vector<f
     return integral;
 }
 
-extern "C" int pm_set_film(pm_ctx* c, const PmFilm* f) {
+extern "C" int pm_set_film(pm_ctx* c, const PmFilm* f, uint32_t struct_bytes) {
     if (!c || !f) return fail(c, PM_ERR_INVALID, "pm_set_film: null argument");
+    PM_ABI_CHECK(c, PmFilm, struct_bytes, "pm_set_film");
     if (c->device < 0) return fail(c, PM_ERR_INVALID, "pm_set_film: host-only context");
     const int w = f->pixel_bounds[2] - f->pixel_bounds[0], h = f->pixel_bounds[3] - f->pixel_bounds[1];
     if (w <= 0 || h <= 0) return fail(c, PM_ERR_INVALID, "pm_set_film: empty pixel_bounds");
@@ -1485,9 +1498,13 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     return PM_OK;
 }
 
-extern "C" int pm_render(pm_ctx* c, const PmRenderParams* p) { return render_impl(c, p, false, 0, 0, 0, nullptr); }
-extern "C" int pm_debug_sample(pm_ctx* c, const PmRenderParams* p, int32_t px, int32_t py, int32_t s, float* out13) {
+extern "C" int pm_render(pm_ctx* c, const PmRenderParams* p, uint32_t struct_bytes) {
+    if (c && p) PM_ABI_CHECK(c, PmRenderParams, struct_bytes, "pm_render");
+    return render_impl(c, p, false, 0, 0, 0, nullptr);
+}
+extern "C" int pm_debug_sample(pm_ctx* c, const PmRenderParams* p, int32_t px, int32_t py, int32_t s, float* out13, uint32_t struct_bytes) {
     if (!out13) return fail(c, PM_ERR_INVALID, "pm_debug_sample: null out");
+    if (c && p) PM_ABI_CHECK(c, PmRenderParams, struct_bytes, "pm_debug_sample");
     return render_impl(c, p, true, px, py, s, out13);
 }
 // test hook: the first n uniforms of the sample stream of (pixel, sample index, dimension), drawn on the device
@@ -1559,8 +1576,9 @@ extern "C" int pm_get_queue_counts(pm_ctx* c, uint64_t* closest, uint64_t* shado
     }
     return PM_OK;
 }
-extern "C" int pm_get_render_stats(pm_ctx* c, PmRenderStats* out) {
+extern "C" int pm_get_render_stats(pm_ctx* c, PmRenderStats* out, uint32_t struct_bytes) {
     if (!c || !out || !c->render) return fail(c, PM_ERR_INVALID, "pm_get_render_stats: nothing rendered");
+    PM_ABI_CHECK(c, PmRenderStats, struct_bytes, "pm_get_render_stats");
     *out = c->render->stats;
     return PM_OK;
 }

@@ -24,17 +24,17 @@ class WavefrontIntegrator:
         self._h = self.aggregate._h
         ck = self.aggregate._check
         mats = scene.c_materials()
-        ck(self._lib.pm_set_materials(self._h, mats, len(scene.materials)))
+        ck(self._lib.pm_set_materials(self._h, mats, len(scene.materials), C.sizeof(_capi.PmMaterial)))
         pmat = scene.c_prim_materials()
         ck(self._lib.pm_set_prim_materials(self._h, pmat.ctypes.data, len(pmat)))
         lights = scene.c_lights()
-        ck(self._lib.pm_set_lights(self._h, lights, len(scene.lights)))
+        ck(self._lib.pm_set_lights(self._h, lights, len(scene.lights), C.sizeof(_capi.PmLight)))
         med = scene.c_medium() if getattr(scene, "medium", None) is not None else None
         if med is not None:
-            ck(self._lib.pm_set_medium(self._h, C.byref(med)))
-        ck(self._lib.pm_set_camera(self._h, C.byref(scene.camera)))
+            ck(self._lib.pm_set_medium(self._h, C.byref(med), C.sizeof(med)))
+        ck(self._lib.pm_set_camera(self._h, C.byref(scene.camera), C.sizeof(scene.camera)))
         film = scene.c_film()
-        ck(self._lib.pm_set_film(self._h, C.byref(film)))
+        ck(self._lib.pm_set_film(self._h, C.byref(film), C.sizeof(film)))
         self.params = PmRenderParams()
         self.params.integrator = integrator
         self.params.max_depth = max_depth
@@ -56,7 +56,7 @@ class WavefrontIntegrator:
     def render(self, window=None, samples=None):
         """Integrate::render() over `window` (x0,y0,x1,y1; default all pixels) and sample indices [s0,s1)."""
         p = self._params(window, samples)
-        self.aggregate._check(self._lib.pm_render(self._h, C.byref(p)))
+        self.aggregate._check(self._lib.pm_render(self._h, C.byref(p), C.sizeof(p)))
         return self.stats()
 
     @staticmethod
@@ -113,7 +113,7 @@ class WavefrontIntegrator:
 
     def stats(self):
         s = PmRenderStats()
-        self.aggregate._check(self._lib.pm_get_render_stats(self._h, C.byref(s)))
+        self.aggregate._check(self._lib.pm_get_render_stats(self._h, C.byref(s), C.sizeof(s)))
         out = {}
         for k, _ in PmRenderStats._fields_:
             v = getattr(s, k)
@@ -132,5 +132,5 @@ class WavefrontIntegrator:
         """(L[4], lambda[4], pdf[4], filter_weight) of one (pixel, sample) — test hook."""
         out = np.zeros(13, np.float32)
         p = self._params(None, None)
-        self.aggregate._check(self._lib.pm_debug_sample(self._h, C.byref(p), px, py, sample_index, out.ctypes.data))
+        self.aggregate._check(self._lib.pm_debug_sample(self._h, C.byref(p), px, py, sample_index, out.ctypes.data, C.sizeof(p)))
         return out

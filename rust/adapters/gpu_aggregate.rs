@@ -12,6 +12,7 @@
 //!     `src/primitives/single.rs:13-19,72-75`);
 //!   * `Sphere::{radius,z_min,z_max,phi_max_degrees,render_from_object,object_from_render,reverse_orientation}()` getters
 //!     (`src/shapes/sphere.rs:19-30`), `BilinearPatch::{mesh_idx,blp_idx}()` (`src/shapes/bilinear_patch.rs:24-28`).
+use std::mem::size_of;
 use std::sync::Arc;
 
 use pbrt_mi355_sys as sys;
@@ -45,6 +46,7 @@ impl GpuAggregate {
     pub fn new(prims: Vec<Arc<PrimitiveEnum>>, max_prims_in_node: u8, split_method: BVHSplitMethod, device_id: i32) -> Self {
         assert!(!prims.is_empty(), "aggregate needs at least one primitive");       // aggregates.rs:60-64
         let mut ctx = std::ptr::null_mut();
+        assert_eq!(unsafe { sys::pm_abi_version() }, sys::PM_ABI_VERSION, "libpbrt_mi355.so and pbrt-mi355-sys disagree on the ABI");
         assert_eq!(unsafe { sys::pm_create(device_id, &mut ctx) }, sys::PM_OK, "no MI355X visible (there is no CPU fallback)");
         let mut first = 0u32;
         let mut i = 0;
@@ -57,7 +59,7 @@ impl GpuAggregate {
                         object_from_render: s.object_from_render().matrix().to_row_major(),
                         reverse_orientation: s.reverse_orientation() as u32, _pad: 0,
                     };
-                    check(ctx, unsafe { sys::pm_add_spheres(ctx, &sp, 1, &mut first) });
+                    check(ctx, unsafe { sys::pm_add_spheres(ctx, &sp, 1, &mut first, size_of::<sys::PmSphere>() as u32) });
                     i += 1;
                 }
                 ShapeEnum::BilinearPatch(p0) => {
@@ -92,7 +94,7 @@ impl GpuAggregate {
             BVHSplitMethod::EqualCounts => sys::PM_SPLIT_EQUAL_COUNTS,
         };
         let mut info = sys::PmAccelInfo::default();
-        check(ctx, unsafe { sys::pm_build_accel(ctx, split, max_prims_in_node as i32, &mut info) });
+        check(ctx, unsafe { sys::pm_build_accel(ctx, split, max_prims_in_node as i32, &mut info, size_of::<sys::PmAccelInfo>() as u32) });
         let b = info.bounds;
         Self { ctx, bounds: Bounds3f::new(Point3f::new(b[0], b[1], b[2]), Point3f::new(b[3], b[4], b[5])), prims }
     }

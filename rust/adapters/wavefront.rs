@@ -13,6 +13,7 @@
 //!     with `DenselySampledSpectrum::new`), `PerspectiveCamera::{camera_from_raster, render_from_camera, lens_radius,
 //!     focal_distance}()` getters, `FilterSampler::table()`, `RGBFilm::load_sums(&[f64])` writing `RGBPixel{rgb_sum,
 //!     weight_sum}` (`camera/film.rs:302-317`).
+use std::mem::size_of;
 use std::sync::Arc;
 
 use pbrt_mi355_sys as sys;
@@ -46,14 +47,14 @@ impl WavefrontIntegrator {
         let mut tables: Vec<Vec<f32>> = Vec::new();
         // materials: one per primitive, in primitive order (material.rs:111-201; constant textures only, as upstream)
         let (mats, prim_mat) = aggregate.flatten_materials(&mut tables);
-        chk(ctx, unsafe { sys::pm_set_materials(ctx, mats.as_ptr(), mats.len() as u32) });
+        chk(ctx, unsafe { sys::pm_set_materials(ctx, mats.as_ptr(), mats.len() as u32, size_of::<sys::PmMaterial>() as u32) });
         chk(ctx, unsafe { sys::pm_set_prim_materials(ctx, prim_mat.as_ptr(), prim_mat.len() as u32) });
         let pm_lights: Vec<sys::PmLight> = lights.iter().map(|l| l.to_pm(&mut tables)).collect();
-        chk(ctx, unsafe { sys::pm_set_lights(ctx, pm_lights.as_ptr(), pm_lights.len() as u32) });
+        chk(ctx, unsafe { sys::pm_set_lights(ctx, pm_lights.as_ptr(), pm_lights.len() as u32, size_of::<sys::PmLight>() as u32) });
         let cam = camera.to_pm();                                   // perspective.rs:20-25, base.rs:260-327
-        chk(ctx, unsafe { sys::pm_set_camera(ctx, &cam) });
+        chk(ctx, unsafe { sys::pm_set_camera(ctx, &cam, size_of::<sys::PmCamera>() as u32) });
         let film = camera.film().to_pm(&mut tables);                // film.rs:108-121, sensor.rs:14-20, filter.rs:177-216
-        chk(ctx, unsafe { sys::pm_set_film(ctx, &film) });
+        chk(ctx, unsafe { sys::pm_set_film(ctx, &film, size_of::<sys::PmFilm>() as u32) });
         let b = camera.film().pixel_bounds();
         let spp = sampler.samples_per_pixel() as i32;
         let params = sys::PmRenderParams {
@@ -75,7 +76,7 @@ fn chk(ctx: *mut sys::pm_ctx, rc: i32) {
 impl Integrate for WavefrontIntegrator {
     fn render(&mut self) {
         let ctx = self.aggregate.ctx;
-        chk(ctx, unsafe { sys::pm_render(ctx, &self.params) });                 // the whole image, every sample index
+        chk(ctx, unsafe { sys::pm_render(ctx, &self.params, size_of::<sys::PmRenderParams>() as u32) });                 // the whole image, every sample index
         let film = self.camera.film_mut();
         let b = film.pixel_bounds();
         let n = ((b.max.x() - b.min.x()) * (b.max.y() - b.min.y())) as usize;

@@ -15,6 +15,7 @@ pub const PM_ERR_NO_ACCEL: i32 = 3;
 pub const PM_ERR_UNSUPPORTED: i32 = 4;
 pub const PM_ERR_STACK_OVERFLOW: i32 = 5;
 pub const PM_MISS: u32 = 0xFFFF_FFFF;
+pub const PM_ABI_VERSION: u32 = 3;
 pub const PM_NOALLOC_MAX_RAYS: u32 = 1 << 18;
 
 pub const PM_SPLIT_HLBVH: i32 = 0;
@@ -218,40 +219,42 @@ pub struct PmRenderStats {
 }
 
 extern "C" {
+    pub fn pm_abi_version() -> u32;
     pub fn pm_create(device_id: i32, out: *mut *mut pm_ctx) -> i32;
     pub fn pm_destroy(ctx: *mut pm_ctx);
     pub fn pm_last_error(ctx: *mut pm_ctx) -> *const c_char;
-    pub fn pm_add_spheres(ctx: *mut pm_ctx, spheres: *const PmSphere, n: u32, first_prim_id: *mut u32) -> i32;
+    pub fn pm_add_spheres(ctx: *mut pm_ctx, spheres: *const PmSphere, n: u32, first_prim_id: *mut u32, struct_bytes: u32) -> i32;
     pub fn pm_add_patch_mesh(ctx: *mut pm_ctx, pos_xyz: *const f32, n_vert: u32, idx4: *const u32, n_patch: u32, normals_or_null: *const f32, reverse_orientation: i32, transform_swaps_handedness: i32, first_prim_id: *mut u32) -> i32;
     pub fn pm_add_patch_mesh_uv(ctx: *mut pm_ctx, pos_xyz: *const f32, n_vert: u32, idx4: *const u32, n_patch: u32, normals_or_null: *const f32, uv_or_null: *const f32, reverse_orientation: i32, transform_swaps_handedness: i32, first_prim_id: *mut u32) -> i32;
     pub fn pm_add_triangle_mesh(ctx: *mut pm_ctx, pos_xyz: *const f32, n_vert: u32, idx3: *const u32, n_tri: u32, first_prim_id: *mut u32) -> i32;
     pub fn pm_clear_geometry(ctx: *mut pm_ctx) -> i32;
-    pub fn pm_build_accel(ctx: *mut pm_ctx, split_method: i32, max_prims_in_node: i32, info_or_null: *mut PmAccelInfo) -> i32;
+    pub fn pm_build_accel(ctx: *mut pm_ctx, split_method: i32, max_prims_in_node: i32, info_or_null: *mut PmAccelInfo, struct_bytes: u32) -> i32;
     pub fn pm_trace_closest(ctx: *mut pm_ctx, rays: *const PmRay, n: u64, out: *mut PmHit) -> i32;
     pub fn pm_trace_any(ctx: *mut pm_ctx, rays: *const PmRay, n: u64, out: *mut u8) -> i32;
     pub fn pm_trace_closest_noalloc(ctx: *mut pm_ctx, d_rays: *const PmRay, n: u64, d_out: *mut PmHit) -> i32;
     pub fn pm_set_counting(ctx: *mut pm_ctx, enabled: i32) -> i32;
     pub fn pm_reset_counters(ctx: *mut pm_ctx) -> i32;
-    pub fn pm_get_counters(ctx: *mut pm_ctx, out: *mut PmCounters) -> i32;
+    pub fn pm_get_counters(ctx: *mut pm_ctx, out: *mut PmCounters, struct_bytes: u32) -> i32;
     pub fn pm_last_kernel_ms(ctx: *mut pm_ctx, ms: *mut f32) -> i32;
     pub fn pm_get_node_buffer(ctx: *mut pm_ctx, data: *mut std::ffi::c_void, cap: u64, needed: *mut u64) -> i32;
     pub fn pm_get_prim_buffer(ctx: *mut pm_ctx, data: *mut std::ffi::c_void, cap: u64, needed: *mut u64) -> i32;
-    pub fn pm_set_materials(ctx: *mut pm_ctx, mats: *const PmMaterial, n: u32) -> i32;
+    pub fn pm_set_materials(ctx: *mut pm_ctx, mats: *const PmMaterial, n: u32, struct_bytes: u32) -> i32;
     pub fn pm_set_prim_materials(ctx: *mut pm_ctx, material_id_per_prim: *const u32, n: u32) -> i32;
-    pub fn pm_set_lights(ctx: *mut pm_ctx, lights: *const PmLight, n: u32) -> i32;
-    pub fn pm_set_medium(ctx: *mut pm_ctx, medium_or_null: *const PmMedium) -> i32;
-    pub fn pm_set_camera(ctx: *mut pm_ctx, cam: *const PmCamera) -> i32;
-    pub fn pm_set_film(ctx: *mut pm_ctx, film: *const PmFilm) -> i32;
-    pub fn pm_render(ctx: *mut pm_ctx, params: *const PmRenderParams) -> i32;
+    pub fn pm_set_lights(ctx: *mut pm_ctx, lights: *const PmLight, n: u32, struct_bytes: u32) -> i32;
+    pub fn pm_set_medium(ctx: *mut pm_ctx, medium_or_null: *const PmMedium, struct_bytes: u32) -> i32;
+    pub fn pm_set_camera(ctx: *mut pm_ctx, cam: *const PmCamera, struct_bytes: u32) -> i32;
+    pub fn pm_set_film(ctx: *mut pm_ctx, film: *const PmFilm, struct_bytes: u32) -> i32;
+    pub fn pm_render(ctx: *mut pm_ctx, params: *const PmRenderParams, struct_bytes: u32) -> i32;
     pub fn pm_film_clear(ctx: *mut pm_ctx) -> i32;
     pub fn pm_film_read(ctx: *mut pm_ctx, rgbw: *mut f64) -> i32;
     pub fn pm_film_add(ctx: *mut pm_ctx, rgbw: *const f64) -> i32;
     pub fn pm_film_image(ctx: *mut pm_ctx, rgb: *mut f32) -> i32;
-    pub fn pm_get_render_stats(ctx: *mut pm_ctx, out: *mut PmRenderStats) -> i32;
+    pub fn pm_get_render_stats(ctx: *mut pm_ctx, out: *mut PmRenderStats, struct_bytes: u32) -> i32;
     pub fn pm_get_queue_counts(ctx: *mut pm_ctx, closest: *mut u64, shadow: *mut u64, cap: u32, n_bounces: *mut u32) -> i32;
-    pub fn pm_debug_sample(ctx: *mut pm_ctx, params: *const PmRenderParams, px: i32, py: i32, sample_index: i32, out13: *mut f32) -> i32;
+    pub fn pm_debug_sample(ctx: *mut pm_ctx, params: *const PmRenderParams, px: i32, py: i32, sample_index: i32, out13: *mut f32, struct_bytes: u32) -> i32;
     pub fn pm_debug_uniforms(ctx: *mut pm_ctx, px: i32, py: i32, seed: u32, sample_index: u64, dimension: u64, n: i32, out: *mut f32) -> i32;
     pub fn pm_debug_math(ctx: *mut pm_ctx, which: i32, x: *const f32, n: i32, out: *mut f32) -> i32;
+    pub fn pm_debug_medium_state(ctx: *mut pm_ctx, out4: *mut f32) -> i32;
 }
 
 // Layout guards: the sizes the C header asserts (include/pbrt_mi355.h, PM_STATIC_ASSERT block).  A field added on one side

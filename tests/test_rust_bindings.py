@@ -51,6 +51,8 @@ def parse_c_header():
         params = []
         for a in " ".join(args.split()).split(","):
             a = a.strip()
+            if a == "void":
+                continue
             m = re.match(r"(const\s+)?(\w+)\s*(\*{0,2})\s*(\w+)$", a)
             const, ty, stars, pname = m.groups()
             base = C_SCALARS[ty][0] if ty in C_SCALARS else ty
@@ -66,6 +68,8 @@ def parse_c_header():
             r = None
         elif ret == "int":
             r = "i32"
+        elif ret in C_SCALARS:
+            r = C_SCALARS[ret][0]
         else:
             r = "*const c_char" if "char" in ret else ret
         funcs[name] = (params, r)
