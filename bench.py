@@ -5,8 +5,10 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 laun
 torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
 
 Workloads (BASELINE.json configs):
-  path    C2 (default, BASELINE.json configs[1]): Cornell box, SimplePathIntegrator(max_depth 5, NEE, BSDF sampling),
-          1024x1024 @ 64 spp per GPU.  A step = one whole Integrate::render() of the image plus — for N>1 — the
+  path    C2 (default, BASELINE.json configs[1]) as SURVEY 8(d) writes it: Cornell box of 36 triangles whose ceiling quad is a
+          diffuse EMITTER (two triangle area lights; no point light), SimplePathIntegrator(max_depth 5, NEE, BSDF sampling),
+          1024x1024 @ 64 spp per GPU.  (c2_point_light: rounds 1-2's variant - a PointLight and a glass sphere - as a leg.)
+          N > 1 also runs c4_strong: C4 at its stated size, 256 spp split over the GPUs.  A step = one whole Integrate::render() of the image plus — for N>1 — the
           film merge.  Metric: path samples/s (`value`).  The default run ALSO measures, each under its own key and each
           with its own roofline and CPU baseline (N=1 only; not `value`):
             closest_hit   C3: 1,048,576-triangle mesh, 4096x4096 primary rays (+ shadow and incoherent ray sets)
@@ -340,17 +342,22 @@ def make_scene(args, pm, workload):
                 f"VolPath: {rw}x{rh}")
         return sd, name, (rw, rh), args.spp or 64, args.max_depth or 16, C.PM_INTEGRATOR_VOL_PATH, args.split or "sah"
     rw = rh = args.res or 1024
-    sd = pm.scenes.cornell_scene((rw, rh))
-    name = f"C2 Cornell box (34 triangles + 1 glass sphere, PointLight: the reference has no area light): {rw}x{rh}"
+    if workload == "c2pl":    # round 1-2's headline scene, kept as a secondary leg
+        sd = pm.scenes.cornell_scene((rw, rh))
+        name = f"C2 variant (34 triangles + 1 glass sphere, PointLight instead of the emitter): {rw}x{rh}"
+        return sd, name, (rw, rh), args.spp or 64, args.max_depth or 5, C.PM_INTEGRATOR_SIMPLE_PATH, args.split or "sah"
+    sd = pm.scenes.c2_scene((rw, rh))
+    name = (f"C2 as SURVEY 8(d) writes it: Cornell box of 36 triangles (5 walls, 2 boxes, ceiling quad EMITTER = 2 triangle "
+            f"DiffuseAreaLights; all diffuse, no point light): {rw}x{rh}")
     return sd, name, (rw, rh), args.spp or 64, args.max_depth or 5, C.PM_INTEGRATOR_SIMPLE_PATH, args.split or "sah"
 
 
-def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup, workload, spp_override=None):
+def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup, workload, spp_override=None, strong=None):
     note(f"building scene ({workload})")
     sd, name, (rw, rh), spp, max_depth, integrator, split = make_scene(args, pm, workload)
     if spp_override:
         spp = spp_override
-    strong = args.scaling == "strong" and world > 1
+    strong = (args.scaling == "strong" if strong is None else strong) and world > 1
     spp_total = spp if strong else spp * world
     integ = pm.WavefrontIntegrator(max_depth, True, True, sd, spp_total, seed=0, device_id=local_rank, integrator=integrator,
                                    split_method=pm._capi.PM_SPLIT_HLBVH if split == "hlbvh" else pm._capi.PM_SPLIT_SAH,
@@ -362,24 +369,35 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup, work
     else:
         window = None
         s0, s1 = pm.distributed.shard_samples(spp_total, rank, world)
-    film = torch.empty((rh, rw, 4), dtype=torch.float64, device="cuda")
+    # N > 1: the film collective of step k runs on RCCL's stream WHILE step k + 1 renders (the library renders on its own
+    # stream into its own film; the merged film lives in one of two torch tensors, used alternately): a buffer is written
+    # again only after the collective that last read it has been waited for
+    films = [torch.empty((rh, rw, 4), dtype=torch.float64, device="cuda") for _ in range(2 if world > 1 else 1)]
+    pending = [None, None]
     merged = {}
+    state = {"k": 0}
 
     def step():
         integ.clear()
         st = integ.render(window=window, samples=(s0, s1))
         if world > 1:
-            # the previous step's collective read `film` on RCCL's stream; it finished long ago (a whole render lies in
-            # between), and this makes that true by construction before the buffer is overwritten
-            torch.cuda.current_stream().synchronize()
-            integ.film(out=film)
+            b = state["k"] & 1
+            state["k"] += 1
+            if pending[b] is not None:
+                pending[b].wait()
+                torch.cuda.current_stream().synchronize()
+            integ.film(out=films[b])
             if rows:
-                merged["film"] = pm.distributed.allgather_rows(film, sd.film["pixel_bounds"])
+                merged["film"], pending[b] = pm.distributed.allgather_rows(films[b], sd.film["pixel_bounds"], async_op=True)
             else:
-                pm.distributed.allreduce_film(film)
+                pending[b] = pm.distributed.allreduce_film(films[b], async_op=True)
         return st
 
     def barrier():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -452,7 +470,8 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup, work
                    "samples_per_gpu": samples, "closest_rays": st["closest_rays"], "shadow_rays": st["shadow_rays"],
                    "passes": st["passes"],
                    "merge": "none" if world == 1 else ("RCCL" if args.backend == "nccl" else args.backend) +
-                            (" all-gather of row bands" if rows else " all-reduce of the f64 film") + " per step",
+                            (" all-gather of row bands" if rows else " all-reduce of the f64 film") +
+                            " per step, overlapped with the next step's render (two film buffers)",
                    "bytes_per_sample": total_bytes / samples,
                    "closest_nodes_per_ray": st_c["closest_nodes"] / max(1, st_c["closest_rays"]),
                    "closest_prims_per_ray": st_c["closest_prims"] / max(1, st_c["closest_rays"]),
@@ -609,14 +628,26 @@ def main():
             out["cpu_baseline"] = cpu_baseline_path(pm, sd, spp, max_depth, cpu_threads(), args.cpu_seconds, integrator, rows)
         integ.aggregate.close()
         del integ, sd
-        if args.workload == "path" and not args.no_secondary:
+        if args.workload == "path" and not args.no_secondary and world > 1:
+            # BASELINE.json configs[3] as it is stated: 3840x2160 @ 256 spp in total, the sample indices split over the N GPUs
+            # (256 / N each), the f64 films merged by one RCCL all-reduce per frame: strong scaling beside the weak C2 value
+            c4s, sd4, integ4, _ = run_path(*ctx, 2, 1, "c4", strong=True)
+            integ4.aggregate.close()
+            del integ4, sd4
+            out["c4_strong"] = sub(c4s)
+            out["c4_strong"]["scaling"] = "strong"
+        if args.workload == "path" and not args.no_secondary and world == 1:
+            pl, sdp, integp, (sppp, dp, ip) = run_path(*ctx, 3, 1, "c2pl")
+            integp.aggregate.close()
+            del integp, sdp
+            out["c2_point_light"] = sub(pl)
             k = max(3, min(args.steps, 5))
             tr = run_trace(*ctx, k, 1, want_cpu)
             out["closest_hit"] = sub(tr)
             for key in ("shadow_any_hit", "incoherent_closest_hit"):
                 if key in tr:
                     out["closest_hit"][key] = tr[key]
-            if world == 1:
+            if True:
                 # the wide-BVH path tracer at C4 scale, one pass of 2^26 paths; and C5 (area light + medium, depth 16)
                 c4, sd4, integ4, (spp4, d4, i4) = run_path(*ctx, 3, 1, "c4", spp_override=8)
                 if want_cpu:

@@ -327,6 +327,17 @@ void ora_renderer_sample(OraRenderer* o, const ORender* rp, int px, int py, int 
     for (int i = 0; i < 4; ++i) { out13[i] = L.v[i]; out13[4 + i] = w.lambda[i]; out13[8 + i] = w.pdf[i]; }
     out13[12] = fw;
 }
+// debugging aid: the rays of ONE (pixel, sample) path, 10 floats each (ref_scene.h ray_log); returns the number of rays
+int ora_renderer_path_log(OraRenderer* o, const ORender* rp, int px, int py, int sample_index, float* out, int max_rays) {
+    std::vector<float> log;
+    Scene::ray_log() = &log;
+    RenderCounters rc; Spec4 L; Wavelengths w; float fw;
+    o->r.eval_pixel_sample(px, py, sample_index, *rp, &rc, &L, &w, &fw);
+    Scene::ray_log() = nullptr;
+    const int n = (int)(log.size() / 10);
+    for (int i = 0; i < n && i < max_rays; ++i) std::memcpy(out + 10 * i, log.data() + 10 * i, 40);
+    return n;
+}
 // PixelSensor::to_sensor_rgb probe (camera/sensor.rs:114-121) for the golden vectors
 void ora_to_sensor_rgb(const float* sensor_bar3x471, float imaging_ratio, const float* L4, const float* lambda4, const float* pdf4, float* rgb3) {
     for (int c = 0; c < 3; ++c) {

@@ -352,8 +352,29 @@ struct Scene {
         bn.clear(); bn.shrink_to_fit();
     }
 
-    // ---------------------------------------------------------------- traversal (aggregates.rs:537-655)
+    // debugging aid of the tests: when set (per thread), every ray traced is appended as 10 floats
+    // {o xyz, d xyz, t_max, kind (0 closest / 1 any), bits of the hit id or of the occlusion flag, t}
+    static std::vector<float>*& ray_log() { static thread_local std::vector<float>* log = nullptr; return log; }
     bool intersect(V3 ro, V3 rd, float t_max, Hit* best, Counters* ctr = nullptr) const {
+        const bool any = intersect_impl(ro, rd, t_max, best, ctr);
+        if (std::vector<float>* log = ray_log()) {
+            float idf; std::memcpy(&idf, &best->prim_id, 4);
+            const float rec[10] = {ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, t_max, 0.0f, idf, any ? best->t : t_max};
+            log->insert(log->end(), rec, rec + 10);
+        }
+        return any;
+    }
+    bool intersect_p(V3 ro, V3 rd, float t_max, Counters* ctr = nullptr) const {
+        const bool occ = intersect_p_impl(ro, rd, t_max, ctr);
+        if (std::vector<float>* log = ray_log()) {
+            const uint32_t o = occ ? 1u : 0u; float of; std::memcpy(&of, &o, 4);
+            const float rec[10] = {ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, t_max, 1.0f, of, 0.0f};
+            log->insert(log->end(), rec, rec + 10);
+        }
+        return occ;
+    }
+    // ---------------------------------------------------------------- traversal (aggregates.rs:537-655)
+    bool intersect_impl(V3 ro, V3 rd, float t_max, Hit* best, Counters* ctr = nullptr) const {
         best->prim_id = 0xFFFFFFFFu;
         if (nodes.empty()) return false;
         float inv[3] = {1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
@@ -382,7 +403,7 @@ struct Scene {
         }
         return any;
     }
-    bool intersect_p(V3 ro, V3 rd, float t_max, Counters* ctr = nullptr) const {
+    bool intersect_p_impl(V3 ro, V3 rd, float t_max, Counters* ctr = nullptr) const {
         if (nodes.empty()) return false;
         float inv[3] = {1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z};
         bool neg[3] = {inv[0] < 0.0f, inv[1] < 0.0f, inv[2] < 0.0f};

@@ -358,6 +358,17 @@ struct WideWalker {
             Group cur{0u, 1u, perm8(1u, oct)};
             found = false;
             *hid = 0xFFFFFFFFu; *ht = t_max; *hu = 0; *hv = 0;
+            // the kernel's tie rule (pm_device.hpp tri_take): the exact triangle test is asked for t <= t_max, and an exact-t tie
+            // with the hit held so far goes to the LOWER primitive id - independent of the order of the tests
+            auto tri_take = [&](uint32_t unit) -> bool {
+                uint32_t id; float t, u, v;
+                if (!test_prim(2, unit, ro, rd, any_hit ? t_max : next_float_up(t_max), &id, &t, &u, &v)) return false;
+                if (t < t_max || (!any_hit && found && t == t_max && id < *hid)) {
+                    t_max = t; found = true; *hid = id; *ht = t; *hu = u; *hv = v;
+                    return true;
+                }
+                return false;
+            };
             for (;;) {
                 if (any_hit && (found || sure)) break;
                 if (cur.pm == 0) {
@@ -424,9 +435,11 @@ struct WideWalker {
                         if (immediate) {
                             if (ctr) ctr->exact_tests++;
                             uint32_t id; float t, u, v;
-                            if (test_prim(type, unit, ro, rd, t_max, &id, &t, &u, &v)) {
+                            if (type == 2) {
+                                if (tri_take(unit)) { if (exact_mode) tcull = rmin(tcull, t_max); }
+                            } else if (test_prim(type, unit, ro, rd, t_max, &id, &t, &u, &v)) {
                                 t_max = t; found = true; *hid = id; *ht = t; *hu = u; *hv = v;
-                                if (type != 2 || exact_mode) tcull = rmin(tcull, t);
+                                tcull = rmin(tcull, t);
                             }
                         }
                     }
@@ -438,8 +451,7 @@ struct WideWalker {
                 if (any_hit && found) break;
                 if (cu.second > tcull) continue;        // behind another certain hit
                 if (ctr) ctr->exact_tests++;
-                uint32_t id; float t, u, v;
-                if (test_prim(2, cu.first, ro, rd, t_max, &id, &t, &u, &v)) { t_max = t; found = true; *hid = id; *ht = t; *hu = u; *hv = v; }
+                (void)tri_take(cu.first);
             }
             bool confirmed = !sure || (found && (any_hit || *ht <= tcull));
             if (confirmed || exact_mode) {

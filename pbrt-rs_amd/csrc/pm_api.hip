@@ -159,7 +159,7 @@ extern "C" int pm_create(int device_id, pm_ctx** out) {
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        pm_memset_sync(c, c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_work, 3 * PM_WORK_SLOTS * sizeof(uint32_t)) != hipSuccess ||
         hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess) {
         delete c;
@@ -512,7 +512,7 @@ extern "C" int pm_set_counting(pm_ctx* c, int enabled) { if (!c) return PM_ERR_I
 extern "C" int pm_reset_counters(pm_ctx* c) {
     if (!c || c->device < 0) return PM_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long)));
+    HIPCHK(c, pm_memset_sync(c, c->d_counters, 8 * sizeof(unsigned long long)));
     c->rays_counted = 0;
     return PM_OK;
 }

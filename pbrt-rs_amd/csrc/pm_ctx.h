@@ -93,6 +93,13 @@ static inline int fail(pm_ctx* c, int code, const std::string& msg) { if (c) c->
         if (e_ != hipSuccess) return fail(c, PM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Zeroing device memory: on the context's own stream and waited for.  (Round 3: pm_film_clear used hipMemset - which for device
+// memory may return before it has run, on the null stream, which does not order against this non-blocking stream - and with
+// four ranks sharing one card the clear landed AFTER the film_add that followed it.)
+static inline hipError_t pm_memset_sync(pm_ctx* c, void* p, size_t bytes) {
+    hipError_t e = hipMemsetAsync(p, 0, bytes, c->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
+}
 static inline bool is_device_ptr(const void* p) {
     hipPointerAttribute_t a;
     hipError_t e = hipPointerGetAttributes(&a, p);

@@ -578,6 +578,20 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
         active = true;
     };
 
+    // Exact-t TIES between triangles resolve to the LOWER primitive id, not to the triangle met first.  Round 3: with parked
+    // leaves the order in which a ray's candidates are tested depends on its wave (a leaf met while the ring is full jumps the
+    // queue), and two triangles hit at bit-equal t - one ray in ~10^7 of the C4 soup - made ONE pixel of the 3840 x 2160 film
+    // differ from run to run.  The exact test is therefore asked for t <= tmax (tie_tmax) and tri_take decides; the result no
+    // longer depends on the order of the tests, on the wave, or on the tree.  (The reference's own answer to such a tie depends
+    // on the order ITS tree visits the two in: the documented tie class.  The CPU mirror follows this rule.)
+    auto tie_tmax = [&]() { return ANY ? tmax : fup(tmax); };
+    auto tri_take = [&](float t, float u, float v, uint32_t id) -> bool {
+        if (t < tmax || (!ANY && found && t == tmax && id < hit.prim_id)) {
+            tmax = t; found = true; hit.prim_id = id; hit.t = t; hit.u = u; hit.v = v;
+            return true;
+        }
+        return false;
+    };
     // pre-filter of one parked triangle (DEFERL): the triangle branch of the leaf loop below, for a unit popped from the ring
     auto drain_one = [&]() {
         const uint32_t unit = cand[(2 * PM_CAND_MAX + (ph & (PM_PEND_MAX > 0 ? PM_PEND_MAX - 1 : 0))) * stride];
@@ -596,9 +610,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                 ++qn;
             } else {                                  // candidate queue full: the exact test at once
                 float t, u, v;
-                if (intersect_tri_exact(ray.o, ray.d, tmax, p00, p10, p01, &t, &u, &v)) {
-                    tmax = t; found = true; hit.prim_id = r2.y; hit.t = t; hit.u = u; hit.v = v;
-                }
+                if (intersect_tri_exact(ray.o, ray.d, tie_tmax(), p00, p10, p01, &t, &u, &v)) (void)tri_take(t, u, v, r2.y);
             }
         }
     };
@@ -662,7 +674,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                     // every lane takes part in the shuffles (a disabled source lane would deliver nothing)
                     const f3 wo = mk3(__shfl(ray.o.x, (int)owner), __shfl(ray.o.y, (int)owner), __shfl(ray.o.z, (int)owner));
                     const f3 wd = mk3(__shfl(ray.d.x, (int)owner), __shfl(ray.d.y, (int)owner), __shfl(ray.d.z, (int)owner));
-                    const float wtmax = __shfl(tmax, (int)owner);
+                    const float wtmax = __shfl(fup(tmax), (int)owner);          // t <= the owner's tmax: ties are the owner's to decide
                     if (work) {
                         const uint4* r = prims + cand_w[j * stride + owner];
                         const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
@@ -674,20 +686,23 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                         if (!intersect_tri_exact(wo, wd, wtmax, v0, v1, v2, &t, &u, &v)) t = INFINITY;
                         cand_w[(PM_CAND_MAX + j) * stride + owner] = __float_as_uint(t);
                         lds_w[j * stride + owner] = make_uint2(__float_as_uint(u), __float_as_uint(v));
-                        reinterpret_cast<uint32_t*>(&lds_w[(4u + (j >> 1)) * stride + owner])[j & 1u] = r2.y;
+                        reinterpret_cast<uint32_t*>(lds_w)[2u * ((4u + (j >> 1)) * stride + owner) + (j & 1u)] = r2.y;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
-                {   // owners apply their results in queue order
-                    uint32_t m = vmask;
-                    while (m) {
-                        const uint32_t j = __ffs(m) - 1u; m &= m - 1u;
+                {   // owners apply their results in queue order (ties: the lower primitive id, see tri_take).  Written out as a
+                    // fixed loop over the four slots: the earlier form - `while (m)` over the set bits calling tri_take - came out
+                    // of hipcc with hit.u / hit.v of the slot BEFORE a tie (ROCm 7.2; tests/test_tie_gpu.py is the regression test)
+#pragma unroll
+                    for (uint32_t j = 0; j < PM_CAND_MAX; ++j) {
+                        if (!(vmask & (1u << j))) continue;
                         const float t = __uint_as_float(cand[(PM_CAND_MAX + j) * stride]);
-                        if (t < tmax) {
-                            const uint2 uv = lds[j * stride];
-                            tmax = t; found = true; hit.t = t; hit.u = __uint_as_float(uv.x); hit.v = __uint_as_float(uv.y);
-                            hit.prim_id = reinterpret_cast<const uint32_t*>(&lds[(4u + (j >> 1)) * stride])[j & 1u];
+                        const uint2 uv = lds[j * stride];
+                        const uint32_t id = reinterpret_cast<const uint32_t*>(lds)[2u * ((4u + (j >> 1)) * stride) + (j & 1u)];
+                        // (INFINITY = the test rejected it: never below a finite tmax, and not taken at tmax = inf while nothing is found)
+                        if (t < tmax || (found && t == tmax && id < hit.prim_id)) {
+                            tmax = t; found = true; hit.prim_id = id; hit.t = t; hit.u = __uint_as_float(uv.x); hit.v = __uint_as_float(uv.y);
                         }
                     }
                 }
@@ -707,9 +722,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                     const f3 v2 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
                     if (COUNT) ctr->exact++;
                     float t, u, v;
-                    if (intersect_tri_exact(ray.o, ray.d, tmax, v0, v1, v2, &t, &u, &v)) {
-                        tmax = t; found = true; hit.prim_id = r2.y; hit.t = t; hit.u = u; hit.v = v;
-                    }
+                    if (intersect_tri_exact(ray.o, ray.d, tie_tmax(), v0, v1, v2, &t, &u, &v)) (void)tri_take(t, u, v, r2.y);
                 }
                 finished = false;
                 // did the exact tests confirm what culling assumed?
@@ -896,8 +909,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                             if (!MIXED && immediate) {      // (triangles only) the queue is full, or the fallback walk
                                 if (COUNT) ctr->exact++;
                                 float t, u, v;
-                                if (intersect_tri_exact(ray.o, ray.d, tmax, p00, p10, p01, &t, &u, &v)) {
-                                    tmax = t; found = true; hit.prim_id = r2.y; hit.t = t; hit.u = u; hit.v = v;
+                                if (intersect_tri_exact(ray.o, ray.d, tie_tmax(), p00, p10, p01, &t, &u, &v) && tri_take(t, u, v, r2.y)) {
                                     if (exact_mode) tcull = fminf(tcull, t);
                                 }
                             }
@@ -911,9 +923,13 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                                 }
                                 if (COUNT) ctr->exact++;
                                 float t, u, v;
-                                if (intersect_patch(ray.o, ray.d, tmax, p00, p10, p01, p11, &t, &u, &v)) {
+                                if (is_tri) {
+                                    if (intersect_patch(ray.o, ray.d, tie_tmax(), p00, p10, p01, p11, &t, &u, &v) && tri_take(t, u, v, id)) {
+                                        if (exact_mode) tcull = fminf(tcull, t);
+                                    }
+                                } else if (intersect_patch(ray.o, ray.d, tmax, p00, p10, p01, p11, &t, &u, &v)) {
                                     tmax = t; found = true; hit.prim_id = id; hit.t = t; hit.u = u; hit.v = v;
-                                    if (!is_tri || exact_mode) tcull = fminf(tcull, t);
+                                    tcull = fminf(tcull, t);
                                 }
                             }
                         }

@@ -458,10 +458,13 @@ __device__ __forceinline__ bool block_regroup(int* kind, uint32_t (&w)[PM_XCH_WO
     return true;
 }
 
-// EXT: the scene holds area lights and / or the integrator is PM_INTEGRATOR_VOL_PATH with a medium set.  That code (emission on
-// a hit, shape sampling, the medium event as a third outcome beside "surface" and "escaped") is compiled only into the EXT
-// variant: it costs registers, and the plain variant is the hot kernel of the C2 / C4 frames.
-template <bool EXT>
+// EXT: the integrator is PM_INTEGRATOR_VOL_PATH with a medium set, or the scene holds textured materials.  That code (the medium
+// event as a third outcome beside "surface" and "escaped", the regrouping of a block's vertices, texture lookups) is compiled only
+// into the EXT variant: it costs registers, and the plain variant is the hot kernel of the C2 / C4 frames.
+// AREA (plain variant only; round 3): the scene holds diffuse area lights but neither a medium nor textures - SURVEY 8(d)'s C2, a
+// Cornell box under a ceiling quad emitter.  The plain straight-line body plus emission on a hit and the shape-sampling branch of
+// sample_light; round 2 sent such scenes through the EXT kernel.
+template <bool EXT, bool AREA = false>
 __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc, SceneArrays sc, PathArrays pa, uint32_t g,
                                                    const uint32_t* __restrict__ count_in,
                                                    uint32_t* __restrict__ count_out, uint32_t* __restrict__ shadow_count) {
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                     }
                     pa.L[slot] = make_float4(L[0], L[1], L[2], L[3]);
                 }
-            } else if (EXT || depth != rc.max_depth) {
+            } else if (AREA || depth != rc.max_depth) {
                 // ---- interaction
                 // (the material record is fetched beside the shading record, not behind the interaction's arithmetic)
                 const uint32_t ref = sc.prim_ref[prim_id];
@@ -528,8 +531,8 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                 SurfInt si;
                 if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], mk3(ro4.x, ro4.y, ro4.z), rd, hv.y);
                 else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
-                // ---- emitted radiance of an area light on this primitive (simple_path.rs:156-158; EXT only)
-                if (EXT && sc.prim_light && (!rc.sample_lights || specular)) {
+                // ---- emitted radiance of an area light on this primitive (simple_path.rs:156-158; AREA instantiation only)
+                if (AREA && sc.prim_light && (!rc.sample_lights || specular)) {
                     const int li = sc.prim_light[prim_id];
                     if (li >= 0) {
                         const DLight lt = sc.lights[li];
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                 }
                 if (depth != rc.max_depth) {
                 depth++;
-                Bsdf bsdf = make_bsdf<EXT>(sc, pa, si, mat, ref, lam, slot, hv.z, hv.w);
+                Bsdf bsdf = make_bsdf<false>(sc, pa, si, mat, ref, lam, slot, hv.z, hv.w);
                 const f3 wo = -rd;
                 // ---- next-event estimation (simple_path.rs:182-213)
                 if (rc.sample_lights) {
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                         f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
                         Spec4 Ls; f3 wi, p_light; float lpdf;
                         const f3 pm = si_p(si);
-                        if (sample_light<EXT>(rc, sc, sc.lights[idx], pm, u2, lam, &Ls, &wi, &lpdf, &p_light) && !spec_zero(Ls) && lpdf > 0.0f) {
+                        if (sample_light<AREA>(rc, sc, sc.lights[idx], pm, u2, lam, &Ls, &wi, &lpdf, &p_light) && !spec_zero(Ls) && lpdf > 0.0f) {
                             Spec4 f = bsdf_eval(bsdf, wo, wi);
                             const float ad = fabsf(dot3(wi, si.ns));
 #pragma unroll
@@ -956,6 +959,29 @@ __global__ __launch_bounds__(RB) void accumulate_kernel(RenderConst rc, SceneArr
     fp[0] = acc[0]; fp[1] = acc[1]; fp[2] = acc[2]; fp[3] = acc[3];
 }
 
+// PBRT_MI355_VERIFY=1 (debugging aid): after every timed closest-hit launch the COUNTING kernel - whose walk does not depend on
+// the wave and equals the CPU mirror's - traces the same queue again, and this kernel compares the two hit arrays
+struct VerifyRec { float o[4], d[4]; float4 timed, counting; uint32_t index, bounce, pad[2]; };
+__global__ void verify_hits_kernel(PathArrays pa, uint32_t g, const uint32_t* __restrict__ count, const float4* __restrict__ timed,
+                                   uint32_t bounce, uint32_t* __restrict__ n_bad, VerifyRec* __restrict__ recs, uint32_t max_recs) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *count) return;
+    const float4 d = pa.rd[g][i];
+    if (__float_as_uint(d.w) == PM_DEAD) return;
+    const float4 a = timed[i], b = pa.hit[i];
+    if (__float_as_uint(a.x) != __float_as_uint(b.x) || __float_as_uint(a.y) != __float_as_uint(b.y) ||
+        __float_as_uint(a.z) != __float_as_uint(b.z) || __float_as_uint(a.w) != __float_as_uint(b.w)) {
+        const uint32_t k = atomicAdd(n_bad, 1u);
+        if (k < max_recs) {
+            const float4 o = pa.ro[g][i];
+            VerifyRec r;
+            r.o[0] = o.x; r.o[1] = o.y; r.o[2] = o.z; r.o[3] = o.w; r.d[0] = d.x; r.d[1] = d.y; r.d[2] = d.z; r.d[3] = d.w;
+            r.timed = a; r.counting = b; r.index = i; r.bounce = bounce; r.pad[0] = 0; r.pad[1] = 0;
+            recs[k] = r;
+        }
+    }
+}
+
 __global__ void film_add_kernel(double* __restrict__ film, const double* __restrict__ other, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) film[i] += other[i];
@@ -1127,7 +1153,7 @@ extern "C" int pm_set_film(pm_ctx* c, const PmFilm* f, uint32_t struct_bytes) {
     if (r->d_film) { HIPCHK(c, hipFree(r->d_film)); r->d_film = nullptr; }
     r->film_pixels = (size_t)w * h;
     HIPCHK(c, hipMalloc((void**)&r->d_film, r->film_pixels * 4 * sizeof(double)));
-    HIPCHK(c, hipMemset(r->d_film, 0, r->film_pixels * 4 * sizeof(double)));
+    HIPCHK(c, pm_memset_sync(c, r->d_film, r->film_pixels * 4 * sizeof(double)));
     if (!r->d_m9) HIPCHK(c, hipMalloc((void**)&r->d_m9, 9 * sizeof(float)));
     HIPCHK(c, hipMemcpy(r->d_m9, f->output_rgb_from_sensor_rgb, 9 * sizeof(float), hipMemcpyHostToDevice));
     r->scene_dirty = true;
@@ -1136,14 +1162,17 @@ extern "C" int pm_set_film(pm_ctx* c, const PmFilm* f, uint32_t struct_bytes) {
 extern "C" int pm_film_clear(pm_ctx* c) {
     if (!c || !c->render || !c->render->d_film) return fail(c, PM_ERR_INVALID, "pm_film_clear: no film");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemset(c->render->d_film, 0, c->render->film_pixels * 4 * sizeof(double)));
+    HIPCHK(c, pm_memset_sync(c, c->render->d_film, c->render->film_pixels * 4 * sizeof(double)));
     return PM_OK;
 }
 extern "C" int pm_film_read(pm_ctx* c, double* out) {
     if (!c || !out || !c->render || !c->render->d_film) return fail(c, PM_ERR_INVALID, "pm_film_read: no film");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy(out, c->render->d_film, c->render->film_pixels * 4 * sizeof(double),
-                        is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    // on the context's stream and waited for: a device-to-device hipMemcpy / hipMemset on the null stream may return before it
+    // has run, and the null stream does not order against this (non-blocking) stream
+    HIPCHK(c, hipMemcpyAsync(out, c->render->d_film, c->render->film_pixels * 4 * sizeof(double),
+                             is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return PM_OK;
 }
 extern "C" int pm_film_add(pm_ctx* c, const double* in) {
@@ -1366,7 +1395,10 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     rc.terminal_emission = (r->n_inf > 0 || r->have_area_lights) ? 1 : 0;
     rc.med_sigma_a = r->med_off_a; rc.med_sigma_s = r->med_off_s; rc.med_g = r->medium.g;
     std::memcpy(rc.med_bounds, r->medium.bounds, sizeof(rc.med_bounds));
-    const bool shade_ext = rc.medium_on || r->have_area_lights || r->have_textures;
+    const bool shade_ext = rc.medium_on || r->have_textures;
+    const bool shade_area = r->have_area_lights && !shade_ext;
+    bool force_ext = false;         // A/B and tests: PBRT_MI355_SHADE_EXT=1 routes area-light scenes through the EXT kernel as round 2 did
+    if (const char* e = std::getenv("PBRT_MI355_SHADE_EXT")) force_ext = std::atoi(e) == 1 && r->have_area_lights;
     {   // SceneData::new -> light.preprocess(scene_bounds): Bounds3f::bounding_sphere (core/bounds.rs:588-597)
         const pm::Box& b = c->accel.bounds;
         float ctr[3], d2 = 0.0f; bool inside = true;
@@ -1389,6 +1421,16 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     unsigned long long cnt_before[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(c, hipMemcpy(cnt_before, c->d_counters, sizeof(cnt_before), hipMemcpyDeviceToHost));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    // PBRT_MI355_VERIFY=1: see verify_hits_kernel
+    bool verify = false;
+    if (const char* e = std::getenv("PBRT_MI355_VERIFY")) verify = std::atoi(e) == 1;
+    float4* verify_hits = nullptr; uint32_t* verify_bad = nullptr; VerifyRec* verify_recs = nullptr;
+    if (verify) {
+        HIPCHK(c, hipMalloc((void**)&verify_hits, max_paths * sizeof(float4)));
+        HIPCHK(c, hipMalloc((void**)&verify_bad, sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc((void**)&verify_recs, 64 * sizeof(VerifyRec)));
+        HIPCHK(c, pm_memset_sync(c, verify_bad, sizeof(uint32_t)));
+    }
     for (int sb = s0; sb < s1; sb += s_per_pass) {
         ev_class.clear();
         rc.s_base = sb; rc.s_count = std::min(s_per_pass, s1 - sb);
@@ -1425,10 +1467,20 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
                 else hipLaunchKernelGGL(closest_fix_kernel<false>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, gen, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
             }
             ++wslot;
+            if (verify && !c->counting && !flat && !has_spheres) {
+                // the same queue through the counting walk (the hits it leaves in pa.hit are the ones the pass goes on with)
+                HIPCHK(c, hipMemcpyAsync(verify_hits, pa.hit, (size_t)npaths * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+                if (wslot + 2 > PM_WORK_SLOTS) { HIPCHK(c, hipMemsetAsync(c->d_work, 0, 3 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream)); wslot = 0; }
+                auto kernel = mixed ? closest_kernel<true, true> : closest_kernel<true, false>;
+                hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, gen, cnt_in, c->d_work + wslot, c->refill, c->d_defer, (uint32_t)c->defer_cap, c->d_counters);
+                ++wslot;
+                hipLaunchKernelGGL(verify_hits_kernel, gr, dim3(RB), 0, c->stream, pa, gen, cnt_in, verify_hits, (uint32_t)b, verify_bad, verify_recs, 64u);
+            }
             mark(2);
             if (random_walk) hipLaunchKernelGGL(shade_rw_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out);
-            else if (shade_ext) hipLaunchKernelGGL(shade_kernel<true>, gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out, cnt_sh);
-            else hipLaunchKernelGGL(shade_kernel<false>, gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out, cnt_sh);
+            else if (shade_ext || force_ext) hipLaunchKernelGGL((shade_kernel<true, false>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out, cnt_sh);
+            else if (shade_area) hipLaunchKernelGGL((shade_kernel<false, true>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out, cnt_sh);
+            else hipLaunchKernelGGL((shade_kernel<false, false>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out, cnt_sh);
             if (!random_walk && p->sample_lights && b < p->max_depth) {
                 mark(3);
                 if (flat) {
@@ -1475,6 +1527,21 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     }
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (verify) {
+        uint32_t n_bad = 0; VerifyRec recs[64];
+        HIPCHK(c, hipMemcpy(&n_bad, verify_bad, sizeof(n_bad), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(recs, verify_recs, sizeof(recs), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[pm verify] %u closest hits of the timed walk differ from the counting walk\n", n_bad);
+        for (uint32_t k = 0; k < n_bad && k < 64; ++k) {
+            const VerifyRec& v = recs[k];
+            uint32_t ob[3], db[3]; std::memcpy(ob, v.o, 12); std::memcpy(db, v.d, 12);
+            uint32_t ta, tb; std::memcpy(&ta, &v.timed.x, 4); std::memcpy(&tb, &v.counting.x, 4);
+            std::fprintf(stderr, "[pm verify] bounce %u entry %u slot %u: o %08x %08x %08x d %08x %08x %08x  timed id %u t %.9g u %.9g v %.9g | counting id %u t %.9g u %.9g v %.9g\n",
+                         v.bounce, v.index, *(const uint32_t*)&v.o[3], ob[0], ob[1], ob[2], db[0], db[1], db[2], ta, v.timed.y, v.timed.z, v.timed.w,
+                         tb, v.counting.y, v.counting.z, v.counting.w);
+        }
+        (void)hipFree(verify_hits); (void)hipFree(verify_bad); (void)hipFree(verify_recs);
+    }
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     r->stats.kernel_ms = ms; c->last_ms = ms;

@@ -33,21 +33,25 @@ def shard_rows(bounds, rank, world, align=8):
     return x0, min(y0 + u0 * align, y1), x1, min(y0 + u1 * align, y1)
 
 
-def allreduce_film(film, group=None):
-    """sample split: film (torch tensor [H, W, 4] f64, device or CPU) summed over ranks in place."""
+def allreduce_film(film, group=None, async_op=False):
+    """sample split: film (torch tensor [H, W, 4] f64, device or CPU) summed over ranks in place.
+    async_op: returns the collective's work handle instead (None for a single rank); the caller renders the next frame while
+    the collective runs and calls .wait() before it touches `film` again."""
     import torch.distributed as dist
+    work = None
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(film, op=dist.ReduceOp.SUM, group=group)
-    return film
+        work = dist.all_reduce(film, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return work if async_op else film
 
 
-def allgather_rows(film, bounds, group=None, align=8):
+def allgather_rows(film, bounds, group=None, align=8, async_op=False):
     """row split: every rank holds a full-size film tensor in which only its own band is filled; returns the
-    assembled film (on every rank)."""
+    assembled film (on every rank).  async_op: returns (assemble, work) instead - the all-gather's handle and a function that
+    builds the assembled film once work.wait() has returned (the caller renders the next frame in between)."""
     import torch
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return film
+        return ((lambda: film), None) if async_op else film
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     x0, y0, x1, y1 = [int(v) for v in bounds]
     wins = [shard_rows(bounds, r, world, align) for r in range(world)]
@@ -56,11 +60,14 @@ def allgather_rows(film, bounds, group=None, align=8):
     w = wins[rank]
     mine[: w[3] - w[1]] = film[w[1] - y0: w[3] - y0]
     parts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine, group=group)
-    out = torch.empty_like(film)
-    for r, w in enumerate(wins):
-        out[w[1] - y0: w[3] - y0] = parts[r][: w[3] - w[1]]
-    return out
+    work = dist.all_gather(parts, mine, group=group, async_op=async_op)
+
+    def assemble():
+        out = torch.empty_like(film)
+        for r, w in enumerate(wins):
+            out[w[1] - y0: w[3] - y0] = parts[r][: w[3] - w[1]]
+        return out
+    return (assemble, work) if async_op else assemble()
 
 
 def render_distributed(integrator, mode="samples", group=None):

@@ -199,8 +199,9 @@ def cornell_scene(resolution=(1024, 1024), spectra=None, glass_sphere=True, area
     """C2: a Cornell box built from triangles (walls, tall box, short box), lit by a PointLight just under the
     ceiling (the reference has no area light, lights/base.rs:18-22), seen through a PerspectiveCamera.
     Optionally one smooth dielectric sphere (divergent specular paths).
-    area_light: instead of the point light, a 0.5 x 0.5 quad emitter (one bilinear patch, DiffuseAreaLight extension)
-    just under the ceiling, facing down.  medium: (sigma_a, sigma_s, g) of a grey homogeneous medium filling the box
+    area_light: instead of the point light, a 0.5 x 0.5 quad emitter (DiffuseAreaLight extension) just under the ceiling,
+    facing down - True: one bilinear patch; "triangles": two triangles of the scene's triangle mesh, each its own light
+    ("Cornell box as triangles ... 1 ceiling quad light").  medium: (sigma_a, sigma_s, g) of a grey homogeneous medium filling the box
     (C5, BASELINE.json configs[4]; render it with PM_INTEGRATOR_VOL_PATH)."""
     from . import host
     from .aggregate import Sphere, TriangleMesh
@@ -245,6 +246,14 @@ def cornell_scene(resolution=(1024, 1024), spectra=None, glass_sphere=True, area
     quad([1, -1, -1], [1, 1, -1], [1, 1, 1], [1, -1, 1], green)        # right
     box((-0.7, -1.0, -0.65), (-0.1, 0.2, -0.05), 17.0, white)           # tall box
     box((0.1, -1.0, 0.0), (0.7, -0.4, 0.6), -18.0, white)               # short box
+    emitter_tris = []
+    if area_light == "triangles":
+        # both normals (v1 - v0) x (v2 - v0) point down (-y): the emitting side faces the room
+        i = len(verts)
+        verts.extend([[-0.25, 0.98, -0.25], [0.25, 0.98, -0.25], [-0.25, 0.98, 0.25], [0.25, 0.98, 0.25]])
+        emitter_tris = [len(tris), len(tris) + 1]
+        tris.extend([[i, i + 1, i + 2], [i + 3, i + 2, i + 1]])
+        mats.extend([white, white])
     pos = _xf_points(rfw.m, np.asarray(verts, f32))
     sd.prims = [TriangleMesh(pos, np.asarray(tris, np.uint32))]
     sd.prim_materials = list(mats)
@@ -253,7 +262,11 @@ def cornell_scene(resolution=(1024, 1024), spectra=None, glass_sphere=True, area
         sd.prims.append(Sphere(0.3, -0.3, 0.3, 360.0, t.m, t.m_inv, False))
         sd.prim_materials.append(glass)
     table = sp.d65.copy()
-    if area_light:
+    if area_light == "triangles":
+        # same radiance as the quad version below: L = 4 I / A with A = 0.25 (the whole quad)
+        scale = f32(4.0 * 4.0 / 0.25) / f32(sp.photometric(table))
+        sd.lights = [host.area_light(table, scale, t, two_sided=False) for t in emitter_tris]
+    elif area_light:
         from .aggregate import BilinearPatchMesh
         # p00 p10 p01 p11 ordered so that dpdu x dpdv points down (-y): the emitting side faces the room
         quad_pos = _xf_points(rfw.m, np.asarray([[-0.25, 0.98, -0.25], [0.25, 0.98, -0.25], [-0.25, 0.98, 0.25], [0.25, 0.98, 0.25]], f32))
@@ -272,6 +285,12 @@ def cornell_scene(resolution=(1024, 1024), spectra=None, glass_sphere=True, area
         sd.medium = host.homogeneous_medium(sp.constant_table(sigma_a), sp.constant_table(sigma_s), 1.0, g,
                                             bounds=tuple(np.minimum(lo, hi)) + tuple(np.maximum(lo, hi)))
     return sd
+
+
+def c2_scene(resolution=(1024, 1024), spectra=None):
+    """BASELINE.json configs[1] as SURVEY 8(d) writes it: the Cornell box as 36 triangles - 5 walls, 2 boxes and the ceiling quad
+    EMITTER (two triangles, one DiffuseAreaLight each: the extension the reference lacks) - all diffuse, no point light."""
+    return cornell_scene(resolution, spectra, glass_sphere=False, area_light="triangles")
 
 
 def c5_scene(resolution=(1024, 1024), spectra=None):

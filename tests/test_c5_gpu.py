@@ -106,3 +106,30 @@ def test_medium_errors(pm):
     integ = pm.WavefrontIntegrator(5, True, True, sd, 4)
     with pytest.raises(pm.PmError):
         integ.render()
+
+
+def test_c2_scene_area_instantiation_bitwise(pm, ora, monkeypatch):
+    """the Cornell box as 36 triangles under a ceiling quad EMITTER (two triangle area lights), all diffuse.
+    Such a scene (area lights, no medium, no textures) runs the AREA instantiation of the plain shade kernel (round 3); the EXT
+    kernel (round 2's routing, PBRT_MI355_SHADE_EXT=1) must give the same film bit for bit."""
+    res, spp = (64, 64), 8
+    sd = pm.scenes.c2_scene(res)
+    assert len(sd.prim_materials) == 36 and len(sd.lights) == 2 and len(sd.prims) == 1
+    frac, tot = _bit_equal(pm, ora, sd, spp)
+    _report("C2 (SURVEY 8d): 36 triangles, ceiling quad emitter, SimplePath depth 5", frac, tot)
+    assert frac >= 0.9999
+    a = pm.WavefrontIntegrator(5, True, True, sd, 4)
+    st = a.render()
+    assert st["shadow_rays"] > 0 and a.aggregate.info.flat_prims == 36
+    monkeypatch.setenv("PBRT_MI355_SHADE_EXT", "1")
+    b = pm.WavefrontIntegrator(5, True, True, sd, 4)
+    b.render()
+    assert np.array_equal(a.film().view(np.uint64), b.film().view(np.uint64))
+    monkeypatch.delenv("PBRT_MI355_SHADE_EXT")
+    # emission is seen directly (camera ray = specular bounce) and found by BSDF sampling when light sampling is off
+    frac, tot = _bit_equal(pm, ora, sd, 4, max_depth=3, sample_lights=False)
+    _report("C2 (SURVEY 8d), sample_lights off", frac, tot)
+    assert frac >= 0.9999
+    # the emitter is visible: the brightest pixels of the image lie on it
+    img = a.image()
+    assert img.max() > 20 * np.median(img)

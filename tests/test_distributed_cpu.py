@@ -55,6 +55,18 @@ def _worker(rank, world, port, out_dir):
         film_rows = d.allgather_rows(torch.from_numpy(oren.film().copy()), sd.film["pixel_bounds"])
         np.save(os.path.join(out_dir, f"samples_{rank}.npy"), film.numpy())
         np.save(os.path.join(out_dir, f"rows_{rank}.npy"), film_rows.numpy())
+        # the asynchronous forms bench.py uses to overlap the collective with the next frame's render: same results
+        oren.clear()
+        oren.render(helpers.render_params(pm, sd, SPP, samples=(s0, s1)), 1)
+        film2 = torch.from_numpy(oren.film().copy())
+        work = d.allreduce_film(film2, async_op=True)
+        oren.clear()
+        oren.render(helpers.render_params(pm, sd, SPP, window=win), 1)          # ("the next frame", while the collective runs)
+        assemble, work2 = d.allgather_rows(torch.from_numpy(oren.film().copy()), sd.film["pixel_bounds"], async_op=True)
+        work.wait()
+        work2.wait()
+        np.save(os.path.join(out_dir, f"samples_async_{rank}.npy"), film2.numpy())
+        np.save(os.path.join(out_dir, f"rows_async_{rank}.npy"), assemble().numpy())
     finally:
         dist.destroy_process_group()
 
@@ -71,3 +83,5 @@ def test_two_rank_split_and_merge(tmp_path):
         np.testing.assert_allclose(a, whole, rtol=1e-14, atol=0)
         b = np.load(tmp_path / f"rows_{r}.npy")
         assert np.array_equal(b.view(np.uint64), whole.view(np.uint64))
+        assert np.array_equal(np.load(tmp_path / f"samples_async_{r}.npy").view(np.uint64), a.view(np.uint64))
+        assert np.array_equal(np.load(tmp_path / f"rows_async_{r}.npy").view(np.uint64), whole.view(np.uint64))

@@ -51,8 +51,9 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_split_and_merge(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_on_one_gpu_split_and_merge(tmp_path, world):
+    """2 and 4 ranks sharing the one card (RES = 72 x 40: five 8-row units over four ranks = ragged row bands 16 / 8 / 8 / 8)"""
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     pm, integ = _integrator()
     integ.render()
@@ -81,3 +82,22 @@ def test_bench_two_ranks(extra):
     total_spp = 4 if extra else 8
     assert f"@ {total_spp} spp in total" in d["config"]["workload"]
     assert "roofline" in d and d["roofline"]["frac"] > 0
+
+
+def test_bench_two_ranks_default_legs():
+    """the DEFAULT N > 1 line (no --no-secondary): the weak C2 value plus the c4_strong leg - BASELINE config 4's split of a
+    fixed sample count over the ranks, films merged by one all-reduce overlapped with the next frame - here at toy size"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--res", "256", "--spp", "4", "--blobs", "8", "--backend", "gloo"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 4000
+    d = json.loads(last)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "@ 8 spp in total" in d["config"]["workload"]
+    leg = d["c4_strong"]
+    assert leg["value"] > 0 and leg["unit"] == "samples/s" and "8192 diffuse triangles" in leg["workload"]
+    full = json.load(open(os.path.join(ROOT, d["full"])))
+    assert full["c4_strong"]["scaling"] == "strong" and "@ 4 spp in total (2 sample indices per GPU)" in full["c4_strong"]["workload"]
+    assert "overlapped" in full["config"]["merge"]

@@ -1,0 +1,173 @@
+"""The BASELINE.json configurations AT THEIR OWN SIZE on the GPU (C4 had no correctness check at all, C2 / C5 were
+checked at 64 x 64 only).
+
+C4 (20,971,520 triangles, device-built tree of ~7 M wide nodes, 63-bit Morton path, 3840 x 2160):
+  * 2^20 primary + 2^20 incoherent + 2^20 shadow rays: the GPU's hits == the CPU walk of the EXPORTED tree bit for bit, and the
+    counting kernels' counters == the CPU walk's; fallback_walks == stack_overflows == 0; any-hit <=> closest-hit consistency;
+  * the reference-layout binary tree (the oracle's BVHAggregate, ~1 min to build) on a 2^15-ray subsample: t / u / v bit-equal;
+  * a 3840 x 2160 render in two passes (PBRT_MI355_PASS_PATHS) == the same render in one pass, bit for bit, and a 64-row band
+    of one sample index == the oracle's film of that band in its correctly-rounded mode (>= 99.99 % of the samples bit-equal).
+C2 (36 triangles, ceiling quad emitter) at 1024 x 1024 @ 64 spp and C5 at 1024 x 1024 @ 8 spp, depth 16:
+  * against the oracle's FAITHFUL mode (glibc f32 transcendentals = what the Rust binary calls) at equal spp and seed:
+    per-pixel relative RMSE <= the bar stated beside each assert, mean image level to 1e-3;
+  * in the correctly-rounded mode two whole sample indices (2 x 1,048,576 samples) >= 99.99 % bit-equal.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+MISS = 0xFFFFFFFF
+THREADS = min(16, len(os.sched_getaffinity(0)))
+
+
+def _log(msg):
+    print(f"[full-size] {msg}", flush=True)
+
+
+def _one_index_bit_equal(pm, ora, integ, oren, sd, spp, s, max_depth, integrator=None, window=None):
+    p = helpers.render_params(pm, sd, spp, max_depth, True, True, samples=(s, s + 1), integrator=integrator, window=window)
+    integ.clear()
+    integ.render(window=window, samples=(s, s + 1))
+    oren.clear()
+    oren.render(p, THREADS)
+    g, o = integ.film(), oren.film()
+    if window is not None:
+        x0, y0, x1, y1 = window
+        bx0, by0 = sd.film["pixel_bounds"][0], sd.film["pixel_bounds"][1]
+        g, o = g[y0 - by0:y1 - by0, x0 - bx0:x1 - bx0], o[y0 - by0:y1 - by0, x0 - bx0:x1 - bx0]
+    assert np.isfinite(g).all()
+    same = (g.view(np.uint64) == o.view(np.uint64)).all(axis=-1)
+    return int(same.sum()), same.size
+
+
+def test_c4_full_size(pm, ora, monkeypatch):
+    t0 = time.time()
+    res = (3840, 2160)
+    sd = pm.scenes.blob_sky_scene(20480, res)
+    _log(f"C4 scene generated in {time.time() - t0:.1f} s")
+    integ = pm.WavefrontIntegrator(5, True, True, sd, 2, split_method=pm._capi.PM_SPLIT_HLBVH)
+    agg = integ.aggregate
+    assert agg.info.n_prims == 20_971_520 and agg.info.flat_prims == 0
+    assert agg.info.build_seconds < 2.0, "the 21 M-triangle tree is built on the device (the host SAH build takes 6.5 s)"
+    _log(f"tree: {agg.info.n_nodes} wide nodes, built on the device in {agg.info.build_seconds:.3f} s")
+    # ---- rays: render space has the camera at the origin and the blobs around (0, 0, 4)
+    centre = np.array([0.0, 0.0, 4.0], np.float32)
+    prim = pm.scenes.primary_rays(1024, 1024, eye=(0.0, 0.0, 0.0))
+    inc = pm.scenes.incoherent_rays(1 << 20, seed=12)
+    inc["o"] += centre
+    hp = agg.intersect(prim)
+    assert 0.3 < (hp["prim_id"] != MISS).mean() < 1.0
+    sh = pm.scenes.shadow_rays(prim, hp, light=(0.0, 3.0, 4.0))
+    rays = np.concatenate([prim, inc, sh])
+    agg.set_counting(True)
+    agg.reset_counters()
+    gpu_c = agg.intersect(rays)
+    ctr = agg.counters()
+    agg.set_counting(False)
+    gpu = agg.intersect(rays)               # the timed kernels (parked leaves, pooled exact tests)
+    assert np.array_equal(gpu.view(np.uint32), gpu_c.view(np.uint32))
+    t1 = time.time()
+    nb, pb = agg.node_buffer(), agg.prim_buffer()
+    assert len(nb) == agg.info.n_nodes * 80 and len(pb) == 20_971_520 * 48
+    cpu, cw = ora.wide_trace(nb, pb, rays, nthreads=THREADS)
+    _log(f"tree exported + CPU walk of {len(rays)} rays in {time.time() - t1:.1f} s; {cw['nodes_visited'] / len(rays):.1f} nodes/ray")
+    assert np.array_equal(gpu.view(np.uint32), cpu.view(np.uint32)), "closest hits differ from the CPU walk of the same tree"
+    for k in ("nodes_visited", "prims_tested", "exact_tests"):
+        assert ctr[k] == cw[k], (k, ctr[k], cw[k])
+    assert ctr["fallback_walks"] == 0 and ctr["stack_overflows"] == 0
+    occ = agg.intersect_p(rays)
+    occ_cpu, _ = ora.wide_trace(nb, pb, rays, any_hit=True, nthreads=THREADS)
+    assert np.array_equal(occ, occ_cpu)
+    assert np.array_equal(occ.astype(bool), gpu["prim_id"] != MISS)
+    del nb, pb
+    hit = gpu["prim_id"] != MISS
+    r2 = rays[hit].copy()
+    r2["tmax"] = gpu["t"][hit] * np.float32(1 + 1e-5)
+    assert agg.intersect_p(r2).all()
+    r3 = rays[hit].copy()
+    r3["tmax"] = gpu["t"][hit] * np.float32(1 - 1e-5)
+    again = agg.intersect(r3)
+    assert ((again["prim_id"] == MISS) | (again["t"] < gpu["t"][hit])).all()
+    # ---- render: two passes == one pass; a row band == the rows of the whole image
+    st1 = integ.render()
+    one = integ.film().copy()
+    assert st1["passes"] == 1 and st1["samples"] == res[0] * res[1] * 2
+    monkeypatch.setenv("PBRT_MI355_PASS_PATHS", str(1 << 23))
+    integ.clear()
+    st2 = integ.render()
+    monkeypatch.delenv("PBRT_MI355_PASS_PATHS")
+    assert st2["passes"] == 2
+    assert np.array_equal(integ.film().view(np.uint64), one.view(np.uint64)), "the film depends on how the samples are cut into passes"
+    assert st2["fallback_walks"] == 0
+    band = (0, 1048, res[0], 1112)
+    integ.clear()
+    integ.render(window=band)
+    fb = integ.film()
+    assert np.array_equal(fb[1048:1112].view(np.uint64), one[1048:1112].view(np.uint64))
+    assert not fb[:1048].any() and not fb[1112:].any()
+    img = one[..., :3] / np.maximum(one[..., 3:], 1e-300)
+    assert np.isfinite(img).all() and img.mean() > 0
+    # ---- the reference-layout tree (oracle's BVHAggregate, Middle split as main.rs uses): a 2^15-ray subsample and one band
+    t2 = time.time()
+    with ora.correctly_rounded():
+        oren = helpers.oracle_renderer_from(sd, ora)
+        _log(f"reference-layout binary BVH of 20,971,520 triangles built in {time.time() - t2:.1f} s")
+        sel = np.random.default_rng(0).choice(len(rays), 1 << 15, replace=False)
+        ref, _ = oren._keep[0].intersect(np.ascontiguousarray(rays[sel]), nthreads=THREADS)
+        g = gpu[sel]
+        for f in ("t", "u", "v"):
+            assert (g[f].view(np.uint32) == ref[f].view(np.uint32)).sum() >= len(sel) - 2, f
+        assert (g["prim_id"] != ref["prim_id"]).sum() <= 2          # exact-t ties only
+        eq, tot = _one_index_bit_equal(pm, ora, integ, oren, sd, 2, 1, 5, window=band)
+    _log(f"[bit-parity] C4 full size, rows 1048..1112, sample index 1: {eq / tot * 100:.4f} % of {tot} samples bit-equal")
+    assert eq / tot >= 0.9999
+    _log(f"C4 full-size test took {time.time() - t0:.1f} s")
+
+
+def _faithful_image_check(pm, ora, sd, spp, max_depth, integrator, name, rmse_bar):
+    kw = {} if integrator is None else {"integrator": integrator}
+    integ = pm.WavefrontIntegrator(max_depth, True, True, sd, spp, **kw)
+    t0 = time.time()
+    oren = helpers.oracle_renderer_from(sd, ora)
+    p = helpers.render_params(pm, sd, spp, max_depth, integrator=integrator)
+    oc = oren.render(p, THREADS)
+    t_cpu = time.time() - t0
+    st = integ.render()
+    gi, oi = integ.image(), oren.image()
+    assert np.isfinite(gi).all() and gi.mean() > 0
+    rmse = helpers.rel_rmse(gi, oi)
+    _log(f"{name}: GPU {st['kernel_ms']:.1f} ms, oracle (faithful mode, {THREADS} threads) {t_cpu:.1f} s; per-pixel rel-RMSE "
+         f"{rmse:.3e} (bar {rmse_bar:.0e}), mean level {gi.mean():.6f} vs {oi.mean():.6f}")
+    assert st["samples"] == oc["samples"]
+    assert abs(st["closest_rays"] - oc["useful_closest_rays"]) <= 1e-3 * oc["closest_rays"]
+    assert abs(gi.mean() - oi.mean()) <= 1e-3 * abs(oi.mean())
+    assert rmse <= rmse_bar
+    # correctly-rounded mode: two whole sample indices, bit for bit
+    with ora.correctly_rounded():
+        oren_cr = oren          # (the transcendental mode is a switch of the oracle library, read at render time)
+        eq = tot = 0
+        for s in (0, spp - 1):
+            e, t = _one_index_bit_equal(pm, ora, integ, oren_cr, sd, spp, s, max_depth, integrator)
+            eq += e
+            tot += t
+    _log(f"[bit-parity] {name}: {eq / tot * 100:.4f} % of {tot} samples bit-equal ({tot - eq} differ)")
+    assert eq / tot >= 0.9999
+
+
+def test_c2_full_size(pm, ora):
+    """BASELINE.json configs[1]: 1024 x 1024 @ 64 spp.  STATED TOLERANCE at this configuration: per-pixel relative RMSE of the GPU
+    image against the oracle's faithful-mode image, equal spp and seed, <= 5e-4 (measured: 4.6e-5; the residue is paths on which a last-ulp libm
+    difference flips a discrete outcome; at 64 spp a flipped path moves its pixel by ~1/64 of a sample's weight)."""
+    _faithful_image_check(pm, ora, pm.scenes.c2_scene((1024, 1024)), 64, 5, None, "C2 1024x1024 @ 64 spp", 5e-4)
+
+
+def test_c5_full_size(pm, ora):
+    """BASELINE.json configs[4]: area light + homogeneous medium, VolPath depth 16, 1024 x 1024 @ 8 spp.  STATED TOLERANCE:
+    per-pixel relative RMSE <= 2e-2 (fewer samples per pixel and up to 17 vertices per path: more flip opportunities)."""
+    _faithful_image_check(pm, ora, pm.scenes.c5_scene((1024, 1024)), 8, 16, pm._capi.PM_INTEGRATOR_VOL_PATH,
+                          "C5 1024x1024 @ 8 spp, depth 16", 2e-2)
