@@ -437,7 +437,7 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup, work
     dom = int(np.argmax(ms_k))
     achieved = bytes_k[dom] / (ms_k[dom] * 1e-3) / 1e9
     total_bytes = float(sum(bytes_k))
-    tag = {"path": "path", "c4": "c4", "c5": "c5"}[workload]
+    tag = {"path": "path", "c2pl": "c2pl", "c4": "c4", "c5": "c5"}[workload]
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "kernel": KERNEL_NAMES[dom], "kernel_ms": float(ms_k[dom] / max(1.0, launches[dom])),
             "launches_per_step": float(launches[dom]), "bytes_per_launch": bytes_k[dom] / max(1.0, launches[dom]),
