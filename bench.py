@@ -20,6 +20,8 @@ Workloads (BASELINE.json configs):
   c4      C4 at full size (3840x2160 @ 256 spp).  --scaling strong splits the 256 spp across the ranks (BASELINE's
           8-GPU configuration: 32 spp per GPU); --merge rows splits the image rows instead and all-gathers the bands.
   c5      C5 alone.
+  patch   closest / any hit over a BilinearPatchMesh of 1,048,576 non-planar patches (the reference's own mesh primitive; tree
+          built on the device, patch-only walk).
 Scaling: weak by default (per-GPU work fixed: rank r renders sample indices [spp*r, spp*(r+1)) of an N*spp image);
 `--scaling strong` fixes the total work.  Films are merged by ONE RCCL all-reduce (or all-gather for --merge rows) per step.
 Inputs (scene, BVH, rays) are resident in HBM before the timed region starts.
@@ -92,7 +94,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="path", choices=["path", "trace", "c4", "c5"])
+    ap.add_argument("--workload", default="path", choices=["path", "trace", "patch", "c4", "c5"])
+    ap.add_argument("--grid", type=int, default=None, help="patch workload: an N x N heightfield with shared vertices instead of the blobs")
     ap.add_argument("--res", type=int, default=None, help="image side (path: 1024, trace: 4096)")
     ap.add_argument("--spp", type=int, default=None, help="samples per pixel per GPU (weak) or in total (strong)")
     ap.add_argument("--max-depth", type=int, default=None)
@@ -140,7 +143,10 @@ def cpu_baseline_trace(pos, idx, rays_sample, threads):
     per-node divides, per-ray heap stack) timed on this box's host cores."""
     ora = _oracle()
     sc = ora.Scene()
-    sc.add_triangle_mesh(pos, idx)
+    if idx.shape[1] == 4:
+        sc.add_patch_mesh(pos, idx, False, False)
+    else:
+        sc.add_triangle_mesh(pos, idx)
     t0 = time.time()
     sc.build(ora.SPLIT_MIDDLE, 255)
     build_s = time.time() - t0
@@ -177,12 +183,22 @@ def cpu_baseline_path(pm, sd, spp, max_depth, threads, seconds, integrator=None,
 
 
 # ------------------------------------------------------------------------------------------------ C3
-def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, want_cpu, secondary=True):
-    res = args.res if (args.res and args.workload == "trace") else 4096
-    blobs = args.blobs if (args.blobs and args.workload == "trace") else 1024
-    pos, idx = pm.scenes.blob_mesh(blobs, 1024, seed=1)
-    split = pm._capi.PM_SPLIT_HLBVH if args.split == "hlbvh" else pm._capi.PM_SPLIT_SAH
-    agg = pm.GpuAggregate([pm.TriangleMesh(pos, idx)], max_prims_in_node=args.max_leaf, device_id=local_rank, split_method=split)
+def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, want_cpu, secondary=True, geom="tri"):
+    res = args.res if (args.res and args.workload in ("trace", "patch")) else 4096
+    blobs = args.blobs if (args.blobs and args.workload in ("trace", "patch")) else 1024
+    if geom == "patch":
+        # the reference's own mesh primitive at C3's scale and in C3's shape: 1024 blobs x 1024 small NON-PLANAR bilinear patches
+        # (--grid N: an N x N heightfield with shared vertices instead)
+        if args.grid:
+            pos, idx = pm.scenes.terrain_patch_mesh(args.grid)
+        else:
+            pos, idx = pm.scenes.blob_patch_mesh(blobs, 1024, seed=1)
+        split = pm._capi.PM_SPLIT_SAH if args.split == "sah" else pm._capi.PM_SPLIT_HLBVH
+        agg = pm.GpuAggregate([pm.BilinearPatchMesh(pos, idx)], max_prims_in_node=args.max_leaf, device_id=local_rank, split_method=split)
+    else:
+        pos, idx = pm.scenes.blob_mesh(blobs, 1024, seed=1)
+        split = pm._capi.PM_SPLIT_HLBVH if args.split == "hlbvh" else pm._capi.PM_SPLIT_SAH
+        agg = pm.GpuAggregate([pm.TriangleMesh(pos, idx)], max_prims_in_node=args.max_leaf, device_id=local_rank, split_method=split)
     rays = pm.scenes.primary_rays(res, res, eye=(0.02 * rank, 0.0, -4.0))
     n_rays = len(rays)
     d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
@@ -195,7 +211,7 @@ def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, wan
     ctr = agg.counters()
     agg.set_counting(False)
     n_node, n_prim = ctr["nodes_visited"] / n_rays, ctr["prims_tested"] / n_rays
-    s_node, s_prim = agg.info.node_bytes, agg.info.prim_record_bytes[2]
+    s_node, s_prim = agg.info.node_bytes, agg.info.prim_record_bytes[1 if geom == "patch" else 2]
     scene_bytes = agg.info.node_buffer_bytes + agg.info.prim_buffer_bytes
     resident = scene_bytes < L3_BYTES
 
@@ -227,22 +243,26 @@ def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, wan
     bpr, demand = bytes_per_ray(n_node, n_prim, 16)
     achieved = bpr * n_rays / (k_ms * 1e-3) / 1e9
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "kernel": "trace_kernel<false,false,false>", "kernel_ms": k_ms, "bytes_per_ray": bpr,
+            "kernel": "trace_kernel<false,false,%s>" % ("PM_WALK_PATCH" if geom == "patch" else "false"), "kernel_ms": k_ms, "bytes_per_ray": bpr,
             "demand_GBps": demand * n_rays / (k_ms * 1e-3) / 1e9, "demand_bytes_per_ray": demand,
             "nodes_per_ray": n_node, "prims_per_ray": n_prim, "scene_bytes": int(scene_bytes),
             "note": ("the %.0f MB scene (nodes + leaf records) stays in the 256 MB Infinity Cache, so the algorithmic HBM bytes are "
                      "the rays and hits alone; the kernel is bound by VALU issue (`issue`), not by HBM" % (scene_bytes / 1e6))
                     if resident else "scene larger than the Infinity Cache: node / record fetches count as HBM bytes (demand)"}
-    roof.update(pmc_fields(r"^trace(_flat)?_kernel<false, false", "trace"))
+    roof.update(pmc_fields(r"^trace(_flat)?_kernel<false, false", "patch" if geom == "patch" else "trace"))
     out = {
         "metric": "closest-hit Mrays/s", "value": n_rays * world * steps / dt / 1e6, "unit": "Mrays/s", "n_gpus": world,
         "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"C3 closest-hit microbench: {len(idx)} triangles ({blobs} blobs x 1024), "
-                               f"{res}x{res} primary rays per GPU in 8x8 tile order",
+        "config": {"workload": (f"bilinear-patch closest-hit microbench (the reference's mesh primitive, C3-shaped): {len(idx)} non-planar "
+                                f"patches ({'heightfield with shared vertices' if args.grid else '%d blobs x 1024' % blobs}), "
+                                f"{res}x{res} primary rays per GPU"
+                                if geom == "patch" else
+                                f"C3 closest-hit microbench: {len(idx)} triangles ({blobs} blobs x 1024), "
+                                f"{res}x{res} primary rays per GPU in 8x8 tile order"),
                    "rays_per_gpu": n_rays, "hit_fraction": hit_frac, "bvh_nodes": int(agg.info.n_nodes),
-                   "bvh_build": args.split or "sah", "bvh_build_seconds": float(agg.info.build_seconds),
-                   "bvh_node_bytes": int(s_node), "tri_record_bytes": int(s_prim),
+                   "bvh_build": args.split or ("hlbvh" if geom == "patch" else "sah"), "bvh_build_seconds": float(agg.info.build_seconds),
+                   "bvh_node_bytes": int(s_node), "prim_record_bytes": int(s_prim),
                    "generator": "numpy PCG64 (default_rng), blob sigma 0.06 (SURVEY 8d says PCG32 streams and 0.02: the tighter "
                                 "blobs leave most primary rays without a hit)"},
         "roofline": roof,
@@ -251,7 +271,7 @@ def run_trace(args, pm, torch, dist, rank, local_rank, world, steps, warmup, wan
         # SURVEY.md 8(d) C3's other two ray sets, each with its own counters and event-timed launches (not `value`)
         hits_host = np.empty(n_rays, dtype=pm.HIT_DTYPE)
         hits_host.view(np.float32).reshape(-1, 4)[:] = d_hits.cpu().numpy()
-        sets = [("shadow_any_hit", pm.scenes.shadow_rays(rays, hits_host), True,
+        sets = [("shadow_any_hit", pm.scenes.shadow_rays(rays, hits_host, light=(0.3, 2.5, -2.0) if geom == "patch" else (0.0, 3.0, 0.0)), True,
                  "any hit from every primary hit point towards a point light at (0,3,0), un-normalised direction, "
                  "t_max = 1 - 1e-4 (primary misses carry t_max = 0)"),
                 ("incoherent_closest_hit", pm.scenes.incoherent_rays(n_rays, seed=2 + rank), False,
@@ -560,10 +580,11 @@ def headline(full, full_path):
     for key in ("c2_point_light", "closest_hit", "c4_path", "c4_strong", "c5_path", "patch_mesh"):
         if key in full:
             h[key] = _leg_short(full[key])
-    ch = full.get("closest_hit", {})
-    for key in ("shadow_any_hit", "incoherent_closest_hit"):
-        if key in ch:
-            h["closest_hit"][key] = {"value": float(f"{ch[key]['value']:.6g}"), "unit": "Mrays/s"}
+    for leg in ("closest_hit", "patch_mesh"):
+        ch = full.get(leg, {})
+        for key in ("shadow_any_hit", "incoherent_closest_hit"):
+            if key in ch and leg in h:
+                h[leg][key] = {"value": float(f"{ch[key]['value']:.6g}"), "unit": "Mrays/s"}
     h["full"] = full_path
     line = json.dumps(h, separators=(",", ":"))
     # never let the line outgrow the driver's tail: shed the optional legs' text first, then the legs
@@ -618,8 +639,8 @@ def main():
     want_cpu = world == 1 and not args.no_cpu_baseline
     ctx = (args, pm, torch, dist, rank, local_rank, world)
 
-    if args.workload == "trace":
-        out = run_trace(*ctx, args.steps, args.warmup, want_cpu)
+    if args.workload in ("trace", "patch"):
+        out = run_trace(*ctx, args.steps, args.warmup, want_cpu, geom="patch" if args.workload == "patch" else "tri")
     else:
         out, sd, integ, (spp, max_depth, integrator) = run_path(*ctx, args.steps, args.warmup, args.workload)
         if want_cpu and rank == 0:
@@ -647,6 +668,11 @@ def main():
             for key in ("shadow_any_hit", "incoherent_closest_hit"):
                 if key in tr:
                     out["closest_hit"][key] = tr[key]
+            pt = run_trace(*ctx, k, 1, want_cpu, geom="patch")
+            out["patch_mesh"] = sub(pt)
+            for key in ("shadow_any_hit", "incoherent_closest_hit"):
+                if key in pt:
+                    out["patch_mesh"][key] = pt[key]
             if True:
                 # the wide-BVH path tracer at C4 scale, one pass of 2^26 paths; and C5 (area light + medium, depth 16)
                 c4, sd4, integ4, (spp4, d4, i4) = run_path(*ctx, 3, 1, "c4", spp_override=8)

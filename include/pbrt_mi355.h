@@ -12,7 +12,9 @@
  * the caller owns all host buffers; the library owns device memory behind pm_ctx;
  * one pm_ctx per GPU; calls on one ctx are serialised by the caller.  Pointers named
  * rays / out / film may be HOST or DEVICE pointers (detected with
- * hipPointerGetAttributes); device pointers are used in place with no copy.
+ * hipPointerGetAttributes); device pointers are used in place with no copy.  Every call is BLOCKING and works on the context's
+ * own (non-blocking) stream: work the caller has queued on other streams for a device buffer it passes in must have finished
+ * (synchronise that stream first), and results are complete when the call returns.
  * Matrices are row-major float[16], m[r*4+c], as SquareMatrix<4> (src/core/square_matrix.rs).
  */
 #ifndef PBRT_MI355_H

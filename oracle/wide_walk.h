@@ -278,6 +278,7 @@ struct WideWalker {
         }
         // spheres and (closest hit) patches AFTER the triangles: pre-filters against the distance a certain triangle hit leaves
         // (any hit: a decided ray skips them); what passes is deferred to the second pass
+        float t_rej = std::numeric_limits<float>::infinity();
         if (!(any_hit && (found || sure))) {
             const float tcs = (cull.cn / cull.cd) * 1.00001f;
             for (uint32_t unit : ft.spheres) {
@@ -295,6 +296,11 @@ struct WideWalker {
                     const float* f = reinterpret_cast<const float*>(prims + (size_t)unit * 16);
                     if (patch_prefilter(ro, inv, R, V3(f[0], f[1], f[2]), V3(f[3], f[4], f[5]), V3(f[6], f[7], f[8]), V3(f[9], f[10], f[11]), tcs))
                         defer_prim(unit | PATCH_TAG);
+                    else {      // the counting kernels' confirm path: the reference arithmetic all the same (pm_device.hpp trace_flat)
+                        if (ctr) ctr->exact_tests++;
+                        uint32_t id; float t, u, v;
+                        if (test_prim(1, unit, ro, rd, ray_tmax, &id, &t, &u, &v)) t_rej = rmin(t_rej, t);
+                    }
                 }
             }
         }
@@ -308,7 +314,8 @@ struct WideWalker {
                 if (any_hit && found) break;
                 (void)test_now(2, cu.unit);
             }
-            if (sure && !(found && (any_hit || *ht <= tconf))) { slow = true; if (ctr) ctr->fallback_walks++; }
+            const bool false_reject = !any_hit && t_rej < (found ? *ht : ray_tmax);
+            if ((sure && !(found && (any_hit || *ht <= tconf))) || false_reject) { slow = true; if (ctr) ctr->fallback_walks++; }
         }
         if (slow) {             // second pass, slow entry: everything again, exactly
             t_max = ray_tmax; found = false;
@@ -360,9 +367,9 @@ struct WideWalker {
             *hid = 0xFFFFFFFFu; *ht = t_max; *hu = 0; *hv = 0;
             // the kernel's tie rule (pm_device.hpp tri_take): the exact triangle test is asked for t <= t_max, and an exact-t tie
             // with the hit held so far goes to the LOWER primitive id - independent of the order of the tests
-            auto tri_take = [&](uint32_t unit) -> bool {
+            auto tri_take = [&](uint32_t unit, uint32_t ptype = 2) -> bool {       // (triangles and patches alike)
                 uint32_t id; float t, u, v;
-                if (!test_prim(2, unit, ro, rd, any_hit ? t_max : next_float_up(t_max), &id, &t, &u, &v)) return false;
+                if (!test_prim(ptype, unit, ro, rd, any_hit ? t_max : next_float_up(t_max), &id, &t, &u, &v)) return false;
                 if (t < t_max || (!any_hit && found && t == t_max && id < *hid)) {
                     t_max = t; found = true; *hid = id; *ht = t; *hu = u; *hv = v;
                     return true;
@@ -437,6 +444,8 @@ struct WideWalker {
                             uint32_t id; float t, u, v;
                             if (type == 2) {
                                 if (tri_take(unit)) { if (exact_mode) tcull = rmin(tcull, t_max); }
+                            } else if (type == 1) {
+                                if (tri_take(unit, 1)) tcull = rmin(tcull, t_max);
                             } else if (test_prim(type, unit, ro, rd, t_max, &id, &t, &u, &v)) {
                                 t_max = t; found = true; *hid = id; *ht = t; *hu = u; *hv = v;
                                 tcull = rmin(tcull, t);

@@ -26,8 +26,8 @@ static std::mutex g_scratch_mutex;                       // contexts may be crea
 static_assert(3 * PM_WORK_SLOTS * sizeof(uint32_t) <= PM_NA_OFF_COUNTERS, "work counters overlap the error counters");
 
 // ------------------------------------------------------------------------------------------ kernels
-template <bool ANY, bool COUNT, bool MIXED>
-__global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR(ANY, MIXED) void trace_kernel(const PmWideNode* __restrict__ nodes,
+template <bool ANY, bool COUNT, int KIND>
+__global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR(ANY, KIND) void trace_kernel(const PmWideNode* __restrict__ nodes,
                                                             const uint4* __restrict__ prims,
                                                             const PmRay* __restrict__ rays, uint32_t n,
                                                             PmHit* __restrict__ hits, uint8_t* __restrict__ occ,
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR(ANY, MIXED) void trace_ke
                                                             uint4* __restrict__ defer_list, uint32_t defer_cap,
                                                             unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TRACE_BLOCK];
-    __shared__ uint32_t cand[PM_CAND_WORDS(ANY, COUNT, MIXED) * TRACE_BLOCK];     // units, then t lower bounds, then the ring of parked leaves
+    __shared__ uint32_t cand[PM_CAND_WORDS(ANY, COUNT, KIND) * TRACE_BLOCK];     // units, then t lower bounds, then the ring of parked leaves
     pmd::TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, pmd::Ray* ray) -> bool {
         const float4* rp = reinterpret_cast<const float4*>(rays + i);
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) PM_TRAV_ATTR(ANY, MIXED) void trace_ke
             *reinterpret_cast<float4*>(hits + i) = o;
         }
     };
-    pmd::trace_persistent<ANY, COUNT, MIXED>(nodes, prims, n, work, refill, stack + threadIdx.x, cand + threadIdx.x, TRACE_BLOCK,
+    pmd::trace_persistent<ANY, COUNT, KIND>(nodes, prims, n, work, refill, stack + threadIdx.x, cand + threadIdx.x, TRACE_BLOCK,
                                       defer_list, work + PM_WORK_SLOTS, defer_cap, &tc, fetch, commit);
 #ifdef PM_DBG_UTIL
     if (true) {
@@ -393,9 +393,9 @@ static void launch_trace(pm_ctx* c, const PmRay* d_rays, uint32_t m, PmHit* oh, 
         hipLaunchKernelGGL(kernel, dim3(fgrid), dim3(TRACE_BLOCK), 0, c->stream, c->flat, c->d_prims, d_rays, m, oh, oo,
                            defer, defer_cap, work + PM_WORK_SLOTS + slot, slow, counters);
     } else {
-        const bool mixed = has_spheres || !c->scene.patches.empty();
-        auto kernel = counting ? (mixed ? trace_kernel<ANY, true, true> : trace_kernel<ANY, true, false>)
-                               : (mixed ? trace_kernel<ANY, false, true> : trace_kernel<ANY, false, false>);
+        const int kind = pm_walk_kind(c);
+        auto kernel = counting ? (kind == PM_WALK_MIXED ? trace_kernel<ANY, true, PM_WALK_MIXED> : kind == PM_WALK_PATCH ? trace_kernel<ANY, true, PM_WALK_PATCH> : trace_kernel<ANY, true, PM_WALK_TRI>)
+                               : (kind == PM_WALK_MIXED ? trace_kernel<ANY, false, PM_WALK_MIXED> : kind == PM_WALK_PATCH ? trace_kernel<ANY, false, PM_WALK_PATCH> : trace_kernel<ANY, false, PM_WALK_TRI>);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(TRACE_BLOCK), 0, c->stream, c->d_nodes, c->d_prims, d_rays, m, oh, oo,
                            work + slot, c->refill, defer, defer_cap, counters);
     }

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -77,6 +78,13 @@ struct pm_ctx {
     RenderState* render = nullptr;   // owned; created lazily by the render entry points
 };
 void pm_render_state_destroy(pm_ctx* c);
+// which walk kernel a scene gets (pm_device.hpp PM_WALK_*): 0 triangles only, 2 bilinear patches only, 1 anything else
+static inline int pm_walk_kind(const pm_ctx* c) {
+    if (!c->scene.spheres.empty()) return 1;
+    if (c->scene.patches.empty()) return 0;
+    if (const char* e = std::getenv("PBRT_MI355_PATCH_WALK")) if (std::atoi(e) == 0) return 1;     // A/B: round 2's routing
+    return c->scene.tris.empty() ? 2 : 1;
+}
 
 static inline int fail(pm_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
 // ABI handshake (pbrt_mi355.h): the caller's sizeof(T) must be the library's

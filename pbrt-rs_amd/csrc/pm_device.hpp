@@ -14,24 +14,27 @@
 namespace pmd {
 
 #define PMD __device__ __forceinline__
+// ... also callable on the host: the few vector helpers with which pm_render.hip precomputes per-light constants in the very
+// arithmetic the kernels (and the reference) use - IEEE operations only, contraction off on both sides
+#define PMHD __host__ __device__ __forceinline__
 
 struct f3 { float x, y, z; };
-PMD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
-PMD f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
-PMD f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
-PMD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
-PMD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
-PMD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
-PMD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-PMD f3 cross3(f3 a, f3 b) {   // f64 products, one narrowing (core/vec.rs:700-712)
+PMHD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PMHD f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PMHD f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PMHD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+PMHD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+PMHD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+PMHD float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PMHD f3 cross3(f3 a, f3 b) {   // f64 products, one narrowing (core/vec.rs:700-712)
     double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z;
     return mk3((float)(ay * bz - az * by), (float)(az * bx - ax * bz), (float)(ax * by - ay * bx));
 }
 PMD f3 lerp3(f3 a, f3 b, float t) { return a * (1.0f - t) + b * t; }
 PMD f3 abs3(f3 a) { return mk3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
 PMD float maxc3(f3 a) { float m = a.x; if (!(a.y < m)) m = a.y; if (!(a.z < m)) m = a.z; return m; }
-PMD float len3(f3 a) { return sqrtf(dot3(a, a)); }
-PMD f3 norm3(f3 a) { return a / len3(a); }
+PMHD float len3(f3 a) { return sqrtf(dot3(a, a)); }
+PMHD f3 norm3(f3 a) { return a / len3(a); }
 
 PMD float fup(float v) {      // next_float_up, core/float.rs:14-36
     if ((isinf(v) && v > 0.0f) || isnan(v)) return v;
@@ -480,7 +483,12 @@ struct SlowWriter {
 #ifndef PM_PEND_ANY
 #define PM_PEND_ANY 1          /* park leaves in the any-hit walk too */
 #endif
-#define PM_CAND_WORDS(ANY, COUNT, MIXED) (2 * PM_CAND_MAX + (((ANY) && !PM_PEND_ANY) || (COUNT) || (MIXED) ? 0 : PM_PEND_MAX))
+#define PM_CAND_WORDS(ANY, COUNT, KIND) (2 * PM_CAND_MAX + (((ANY) && !PM_PEND_ANY) || (COUNT) || (KIND) == PM_WALK_MIXED ? 0 : PM_PEND_MAX))
+// what a walk kernel is compiled for (template argument KIND of trace_persistent; `false` / `true` still mean TRI / MIXED)
+#define PM_WALK_TRI 0        /* the scene holds triangles only */
+#define PM_WALK_MIXED 1      /* spheres, or several primitive types: no parked leaves; spheres deferred to the second pass */
+#define PM_WALK_PATCH 2      /* bilinear patches only (round 3): leaves are parked like triangles' and the reference-arithmetic patch
+                                test runs in the shared flush trips instead of inside the node step */
 #ifndef PM_PEND_FLUSH
 #define PM_PEND_FLUSH 24
 #endif
@@ -526,11 +534,12 @@ PMD float safe_rcp_dir(float d) { return fabsf(d) < 1e-18f ? copysignf(1e18f, d)
 //   commit(i, found, hit)    store the result of work item i
 // `lds` is this lane's column of the per-block LDS stack (entry e at lds[e * stride]); `cand` this lane's column of the
 // candidate queue.
-template <bool ANY, bool COUNT, bool MIXED, class FetchFn, class CommitFn>
+template <bool ANY, bool COUNT, int KIND, class FetchFn, class CommitFn>
 PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __restrict__ prims, uint32_t n_items,
                           uint32_t* __restrict__ work_counter, uint32_t refill, uint2* lds, uint32_t* cand, int stride,
                           uint4* __restrict__ defer_list, uint32_t* __restrict__ defer_count, uint32_t defer_cap,
                           TravCounters* ctr, FetchFn fetch, CommitFn commit) {
+    constexpr bool MIXED = KIND == PM_WALK_MIXED, PONLY = KIND == PM_WALK_PATCH;
     const float widen = 1.0f + 2.0f * gamma_n(3);
     const uint32_t lane = threadIdx.x & 63u;
     // perm8 for every (octant, mask) as a 2 KB table in LDS: one ds_read_u8 instead of ~15 VALU instructions, twice per node
@@ -558,7 +567,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
     constexpr bool DEFERL = PM_PEND_MAX > 0 && (PM_PEND_ANY || !ANY) && !COUNT && !MIXED;
     // Pooled exact tests (closest hit, triangle-only scenes): see the refill phase.  The finished lanes' candidates are
     // dealt out over ALL lanes of the wave, one (ray, triangle) pair each.
-    constexpr bool POOL = PM_POOL_EXACT && !ANY && !MIXED && PM_LDS_STACK >= 6 && PM_CAND_MAX == 4;
+    constexpr bool POOL = PM_POOL_EXACT && !ANY && KIND == PM_WALK_TRI && PM_LDS_STACK >= 6 && PM_CAND_MAX == 4;
     __shared__ uint8_t pool_pairs[(POOL ? 4 : 1) * 64];        // per wave: (owner lane << 2 | candidate) of the pairs in flight
     uint8_t* const my_pairs = pool_pairs + (POOL ? (threadIdx.x >> 6) * 64u : 0u);
     uint2* const lds_w = lds - lane;                           // the wave's base of the strided per-lane arrays
@@ -601,6 +610,14 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
         const f3 p00 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
         const f3 p10 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
         const f3 p01 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
+        if (PONLY) {        // a parked PATCH: the reference arithmetic now, with whoever else has one parked (no float pre-filter
+                            // exists for the bilinear test; its box test was the node step's - the leaf's own quantised box)
+            const uint4 r3 = r[3];
+            const f3 p11 = mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
+            float t, u, v;
+            if (intersect_patch(ray.o, ray.d, tie_tmax(), p00, p10, p01, p11, &t, &u, &v) && tri_take(t, u, v, r3.x)) tcull = fminf(tcull, t);
+            return;
+        }
         float th, tl;
         const int cls = tri_prefilter(ray.o, ray.d, R, D, p00, p10, p01, tcull, &th, &tl);
         if (cls != 0) {
@@ -906,14 +923,14 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                                     }
                                 }
                             }
-                            if (!MIXED && immediate) {      // (triangles only) the queue is full, or the fallback walk
+                            if (KIND == PM_WALK_TRI && immediate) {      // (triangles only) the queue is full, or the fallback walk
                                 if (COUNT) ctr->exact++;
                                 float t, u, v;
                                 if (intersect_tri_exact(ray.o, ray.d, tie_tmax(), p00, p10, p01, &t, &u, &v) && tri_take(t, u, v, r2.y)) {
                                     if (exact_mode) tcull = fminf(tcull, t);
                                 }
                             }
-                            if (MIXED && immediate) {    // patches; triangles when the queue is full or in the fallback walk
+                            if (KIND != PM_WALK_TRI && immediate) {    // patches; triangles when the queue is full or in the fallback walk
                                 f3 p11 = p01;
                                 uint32_t id = r2.y;
                                 if (!is_tri) {
@@ -927,9 +944,8 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                                     if (intersect_patch(ray.o, ray.d, tie_tmax(), p00, p10, p01, p11, &t, &u, &v) && tri_take(t, u, v, id)) {
                                         if (exact_mode) tcull = fminf(tcull, t);
                                     }
-                                } else if (intersect_patch(ray.o, ray.d, tmax, p00, p10, p01, p11, &t, &u, &v)) {
-                                    tmax = t; found = true; hit.prim_id = id; hit.t = t; hit.u = u; hit.v = v;
-                                    tcull = fminf(tcull, t);
+                                } else if (intersect_patch(ray.o, ray.d, tie_tmax(), p00, p10, p01, p11, &t, &u, &v) && tri_take(t, u, v, id)) {
+                                    tcull = fminf(tcull, t);        // (patches follow the triangles' tie rule: a parked patch may be tested late)
                                 }
                             }
                         }
@@ -1102,6 +1118,14 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
                     defer_prim(unit);
             }
         }
+        // CONFIRM PATH of the patch pre-filter (counting kernels, i.e. every test that compares counters): a patch the pre-filter
+        // rejects is put through the reference arithmetic all the same, and should that hit lie in front of what the ray ends up
+        // with, the ray is counted in `fallback` and redone exactly by the second pass.  So a false reject can neither pass a
+        // counting run unnoticed nor falsify its result; the timed kernels skip the check.  (Why none is expected: the reference
+        // only runs its patch test for rays that pass ITS slab test of the same corner box - the leaf bounds of its BVH,
+        // bilinear_patch.rs:176-181, bounds.rs:381-404, widened by 1 + 2 gamma(3) ~ 4e-7 - and patch_prefilter pads that box by
+        // 1e-4 of the coordinates and compares with a relative slack of 1e-4: it accepts a superset.)
+        float t_rej = INFINITY;
         if (PATCH && !ANY) {        // (round 1 ran the reference arithmetic at once, for every ray and every patch: ~300 instructions each)
             const f3 pinv = mk3(safe_rcp_dir(ray.d.x), safe_rcp_dir(ray.d.y), safe_rcp_dir(ray.d.z));
             for (uint32_t i = 0; i < fs.n_patch; ++i) {
@@ -1110,11 +1134,16 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
                     if (COUNT) ctr->prims++;
                     const cuint4_p r = as_uniform(prims + unit);
                     const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
-                    if (patch_prefilter(ray.o, pinv, R, mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)),
-                                        mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y)),
-                                        mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x)),
-                                        mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w)), tcs))
-                        defer_prim(unit | PM_DEFER_PATCH);
+                    const f3 q00 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
+                    const f3 q10 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
+                    const f3 q01 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
+                    const f3 q11 = mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
+                    if (patch_prefilter(ray.o, pinv, R, q00, q10, q01, q11, tcs)) defer_prim(unit | PM_DEFER_PATCH);
+                    else if (COUNT) {
+                        ctr->exact++;
+                        float t, u, v;
+                        if (intersect_patch(ray.o, ray.d, ray.tmax, q00, q10, q01, q11, &t, &u, &v)) t_rej = fminf(t_rej, t);
+                    }
                 }
             }
         }
@@ -1150,7 +1179,8 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
             }
         }
         // ---- did the exact tests confirm what culling assumed?  If not the ray is slow too (counted; never seen)
-        const bool unconfirmed = live && !slow && sure && !(found && (ANY || hit.t <= tconf));
+        const bool false_reject = COUNT && PATCH && !ANY && live && !slow && t_rej < (found ? hit.t : ray.tmax);
+        const bool unconfirmed = (live && !slow && sure && !(found && (ANY || hit.t <= tconf))) || false_reject;
         if (COUNT && unconfirmed) ctr->fallback++;
         // ---- commit.  Closest hit: what the triangles gave is committed now and the second pass improves it with the
         // deferred primitives.  Any hit: a ray occluded by a triangle is final; one with deferred primitives is committed by

@@ -1,4 +1,5 @@
-// GPU build of the wide quantised BVH for triangle scenes (PM_SPLIT_HLBVH).
+// GPU build of the wide quantised BVH for triangle scenes and - round 3 - for bilinear-patch scenes (PM_SPLIT_HLBVH): the
+// reference's only mesh primitive is the BilinearPatchMesh (shapes/bilinear_patch.rs:615-707).
 //
 // The reference's BVHSplitMethod::HLBVH path (primitives/aggregates.rs:273-474: Morton codes -> radix sort -> LBVH
 // treelets -> SAH upper tree) is broken upstream; closest-hit results do not depend on the tree, so what
@@ -27,6 +28,27 @@ namespace {
 
 struct GBox { float lo[3], hi[3]; };
 static_assert(sizeof(pm::HostTri) == 64, "HostTri is uploaded as is");
+// what the build needs of a bilinear patch (pm::HostPatch carries normals and uv as well): corners, id, flags, bounds
+struct GBPatch { float p[4][3]; uint32_t prim_id; uint32_t flags; pm::Box bounds; };
+static_assert(sizeof(GBPatch) == 80, "GBPatch");
+// per primitive type: the leaf record and how it is written
+template <class P> struct GBTraits;
+template <> struct GBTraits<pm::HostTri> {
+    using Rec = PmTriRecord;
+    static constexpr uint32_t UNITS = PM_UNITS_TRI, TYPE = PM_PRIM_TRI;
+    static __device__ __forceinline__ void write(Rec& r, const pm::HostTri& tr) {
+        for (int k = 0; k < 3; ++k) { r.v0[k] = tr.v[0][k]; r.v1[k] = tr.v[1][k]; r.v2[k] = tr.v[2][k]; }
+        r.prim_id = tr.prim_id; r.pad[0] = 0; r.pad[1] = 0;
+    }
+};
+template <> struct GBTraits<GBPatch> {
+    using Rec = PmPatchRecord;
+    static constexpr uint32_t UNITS = PM_UNITS_PATCH, TYPE = PM_PRIM_PATCH;
+    static __device__ __forceinline__ void write(Rec& r, const GBPatch& pt) {
+        for (int k = 0; k < 3; ++k) { r.p00[k] = pt.p[0][k]; r.p10[k] = pt.p[1][k]; r.p01[k] = pt.p[2][k]; r.p11[k] = pt.p[3][k]; }
+        r.prim_id = pt.prim_id; r.flags = pt.flags; r.pad[0] = 0; r.pad[1] = 0;
+    }
+};
 
 __device__ __forceinline__ unsigned long long spread21(unsigned long long x) {   // 21 bits -> every third bit
     x &= 0x1FFFFFull;
@@ -38,7 +60,8 @@ __device__ __forceinline__ unsigned long long spread21(unsigned long long x) {  
     return x;
 }
 
-__global__ void morton_kernel(const pm::HostTri* __restrict__ tris, uint32_t n, GBox scene, unsigned long long* __restrict__ keys,
+template <class P>
+__global__ void morton_kernel(const P* __restrict__ tris, uint32_t n, GBox scene, unsigned long long* __restrict__ keys,
                               uint32_t* __restrict__ vals) {
     const uint32_t i = blockIdx.x * GB_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -94,7 +117,8 @@ __global__ void radix_tree_kernel(const unsigned long long* __restrict__ keys, i
     if (i == 0) parent_of_internal[0] = 0xFFFFFFFFu;
 }
 
-__device__ __forceinline__ GBox box_of(uint32_t ref, const GBox* ibox, const pm::HostTri* __restrict__ tris,
+template <class P>
+__device__ __forceinline__ GBox box_of(uint32_t ref, const GBox* ibox, const P* __restrict__ tris,
                                        const uint32_t* __restrict__ sorted) {
     if (ref & GB_LEAF_FLAG) {
         const pm::Box& b = tris[sorted[ref & ~GB_LEAF_FLAG]].bounds;
@@ -112,7 +136,8 @@ __device__ __forceinline__ GBox box_of(uint32_t ref, const GBox* ibox, const pm:
 // min / max are exact and associative, so the boxes are bit-identical to a bottom-up refit.  Round 1's refit (one thread per
 // leaf climbing the tree, an atomic and two agent-scope fences per level) took 134 ms of the 256 ms build of the 21 M-triangle
 // scene; this takes a few ms and K * n * 24 bytes of scratch (12.6 GB for that scene: the device has 288 GB).
-__global__ void leafbox_kernel(const pm::HostTri* __restrict__ tris, const uint32_t* __restrict__ sorted, int n, GBox* __restrict__ out) {
+template <class P>
+__global__ void leafbox_kernel(const P* __restrict__ tris, const uint32_t* __restrict__ sorted, int n, GBox* __restrict__ out) {
     const int i = blockIdx.x * GB_BLOCK + threadIdx.x;
     if (i >= n) return;
     const pm::Box& b = tris[sorted[i]].bounds;
@@ -182,15 +207,17 @@ __device__ void quantise_node_dev(PmWideNode& wn, const GBox& nb, const GBox* cb
     }
 }
 
+template <class P>
 struct CollapseArgs {
-    const pm::HostTri* tris; const uint32_t* sorted; const uint2* children; const uint2* range; const GBox* ibox;
-    PmWideNode* nodes; uint32_t node_cap; PmTriRecord* records;
+    const P* tris; const uint32_t* sorted; const uint2* children; const uint2* range; const GBox* ibox;
+    PmWideNode* nodes; uint32_t node_cap; typename GBTraits<P>::Rec* records;
     uint32_t* node_counter; uint32_t* rec_counter; uint32_t* overflow;
     int max_leaf;
 };
 
 // one thread per wide node of this level: in[] = (wide index, binary ref); out[] receives the interior children
-__global__ void collapse_kernel(CollapseArgs a, const uint2* __restrict__ in, uint32_t n_in, uint2* __restrict__ out,
+template <class P>
+__global__ void collapse_kernel(CollapseArgs<P> a, const uint2* __restrict__ in, uint32_t n_in, uint2* __restrict__ out,
                                 uint32_t* __restrict__ out_count) {
     const uint32_t t = blockIdx.x * GB_BLOCK + threadIdx.x;
     if (t >= n_in) return;
@@ -249,7 +276,7 @@ __global__ void collapse_kernel(CollapseArgs a, const uint2* __restrict__ in, ui
     const uint32_t rec_base = n_rec ? atomicAdd(a.rec_counter, n_rec) : 0u;
     if (child_base + n_int > a.node_cap) { atomicExch(a.overflow, 1u); return; }
     wn.child_base = child_base;
-    wn.prim_base = (rec_base * PM_UNITS_TRI) | ((uint32_t)PM_PRIM_TRI << 30);
+    wn.prim_base = (rec_base * GBTraits<P>::UNITS) | (GBTraits<P>::TYPE << 30);
     const uint32_t out_base = n_int ? atomicAdd(out_count, n_int) : 0u;
     uint32_t rank = 0, rec_off = 0;
     for (int s = 0; s < 8; ++s) {
@@ -264,10 +291,8 @@ __global__ void collapse_kernel(CollapseArgs a, const uint2* __restrict__ in, ui
             else { first = a.range[ref].x; count = a.range[ref].y - first + 1u; }
             wn.meta[s] = (uint8_t)((count << 5) | rec_off);
             for (uint32_t i = 0; i < count; ++i) {
-                const pm::HostTri& tr = a.tris[a.sorted[first + i]];
-                PmTriRecord r;
-                for (int k = 0; k < 3; ++k) { r.v0[k] = tr.v[0][k]; r.v1[k] = tr.v[1][k]; r.v2[k] = tr.v[2][k]; }
-                r.prim_id = tr.prim_id; r.pad[0] = 0; r.pad[1] = 0;
+                typename GBTraits<P>::Rec r;
+                GBTraits<P>::write(r, a.tris[a.sorted[first + i]]);
                 a.records[rec_base + rec_off + i] = r;
             }
             rec_off += count;
@@ -291,13 +316,11 @@ struct DevBuf {
         if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); return PM_ERR_HIP; }    \
     } while (0)
 
-// Builds the tree of a triangles-only scene on the device.  On success c->d_nodes / c->d_prims hold it and c->accel holds
-// host copies (for pm_get_node_buffer / pm_get_prim_buffer).  Returns PM_ERR_UNSUPPORTED when the scene does not qualify
-// (the caller then uses the host builder).
-int pm_gpu_build_tris(pm_ctx* c, int max_leaf, std::string& err) {
-    const pm::HostScene& sc = c->scene;
-    const size_t n = sc.tris.size();
-    if (!sc.spheres.empty() || !sc.patches.empty() || n < 4096 || n > 0x3FFFFFFFull / PM_UNITS_TRI) return PM_ERR_UNSUPPORTED;
+// Builds the tree of a scene of ONE primitive type (host array `prims` of n triangles or patches) on the device.  On success
+// c->d_nodes / c->d_prims hold it; host copies are fetched on demand (pm_get_node_buffer / pm_get_prim_buffer).
+template <class P>
+static int gpu_build(pm_ctx* c, const P* prims, size_t n, int max_leaf, std::string& err) {
+    using Rec = typename GBTraits<P>::Rec;
     const auto t0 = std::chrono::steady_clock::now();
     // Leaves of a linear BVH are runs of the Morton order, not SAH clusters: their boxes are loose, and every extra
     // primitive in a leaf is an extra pre-filter test for each ray that touches the box.  Measured on the C3 geometry
@@ -309,16 +332,16 @@ int pm_gpu_build_tris(pm_ctx* c, int max_leaf, std::string& err) {
     if (const char* e = std::getenv("PBRT_MI355_LBVH_LEAF")) { const int v = std::atoi(e); if (v >= 1 && v <= PM_MAX_LEAF) max_leaf = v; }
     GBox scene;
     for (int k = 0; k < 3; ++k) { scene.lo[k] = INFINITY; scene.hi[k] = -INFINITY; }
-    for (const auto& t : sc.tris)
-        for (int k = 0; k < 3; ++k) { scene.lo[k] = std::fmin(scene.lo[k], t.bounds.lo[k]); scene.hi[k] = std::fmax(scene.hi[k], t.bounds.hi[k]); }
+    for (size_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) { scene.lo[k] = std::fmin(scene.lo[k], prims[i].bounds.lo[k]); scene.hi[k] = std::fmax(scene.hi[k], prims[i].bounds.hi[k]); }
 
     hipStream_t st = c->stream;
     DevBuf tris, keys, keys2, vals, vals2, temp, children, range, par_i, par_l, ibox, q0, q1, counters, big_nodes;
-    GBCHK(tris.alloc(n * sizeof(pm::HostTri)));
-    GBCHK(hipMemcpyAsync(tris.p, sc.tris.data(), n * sizeof(pm::HostTri), hipMemcpyHostToDevice, st));
+    GBCHK(tris.alloc(n * sizeof(P)));
+    GBCHK(hipMemcpyAsync(tris.p, prims, n * sizeof(P), hipMemcpyHostToDevice, st));
     GBCHK(keys.alloc(n * 8)); GBCHK(keys2.alloc(n * 8)); GBCHK(vals.alloc(n * 4)); GBCHK(vals2.alloc(n * 4));
     const uint32_t grid_n = (uint32_t)((n + GB_BLOCK - 1) / GB_BLOCK);
-    hipLaunchKernelGGL(morton_kernel, dim3(grid_n), dim3(GB_BLOCK), 0, st, tris.as<pm::HostTri>(), (uint32_t)n, scene,
+    hipLaunchKernelGGL(morton_kernel<P>, dim3(grid_n), dim3(GB_BLOCK), 0, st, tris.as<P>(), (uint32_t)n, scene,
                        keys.as<unsigned long long>(), vals.as<uint32_t>());
     size_t temp_bytes = 0;
     GBCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys.as<unsigned long long>(), keys2.as<unsigned long long>(),
@@ -342,7 +365,7 @@ int pm_gpu_build_tris(pm_ctx* c, int max_leaf, std::string& err) {
             return PM_ERR_UNSUPPORTED;
         }
         GBox* T = table.as<GBox>();
-        hipLaunchKernelGGL(leafbox_kernel, dim3(grid_n), dim3(GB_BLOCK), 0, st, tris.as<pm::HostTri>(), vals2.as<uint32_t>(), (int)n, T);
+        hipLaunchKernelGGL(leafbox_kernel<P>, dim3(grid_n), dim3(GB_BLOCK), 0, st, tris.as<P>(), vals2.as<uint32_t>(), (int)n, T);
         for (int k = 1; k < levels; ++k)
             hipLaunchKernelGGL(rmq_level_kernel, dim3(grid_n), dim3(GB_BLOCK), 0, st, T + (size_t)(k - 1) * n, T + (size_t)k * n, (int)n,
                                1 << (k - 1));
@@ -356,21 +379,21 @@ int pm_gpu_build_tris(pm_ctx* c, int max_leaf, std::string& err) {
     const uint32_t node_cap = (uint32_t)n;
     GBCHK(big_nodes.alloc((size_t)node_cap * sizeof(PmWideNode)));
     void* d_records = nullptr;
-    GBCHK(hipMalloc(&d_records, n * sizeof(PmTriRecord)));
+    GBCHK(hipMalloc(&d_records, n * sizeof(Rec)));
     DevBuf rec_guard; rec_guard.p = d_records;
     GBCHK(q0.alloc((size_t)node_cap * 8)); GBCHK(q1.alloc((size_t)node_cap * 8)); GBCHK(counters.alloc(16));
     const uint32_t init[4] = {1u /* node counter: the root is node 0 */, 0u /* records */, 0u /* overflow */, 0u /* level out count */};
     GBCHK(hipMemcpyAsync(counters.p, init, sizeof(init), hipMemcpyHostToDevice, st));
     const uint2 root_entry = make_uint2(0u, 0u);
     GBCHK(hipMemcpyAsync(q0.p, &root_entry, sizeof(root_entry), hipMemcpyHostToDevice, st));
-    CollapseArgs ca{tris.as<pm::HostTri>(), vals2.as<uint32_t>(), children.as<uint2>(), range.as<uint2>(), ibox.as<GBox>(),
-                    big_nodes.as<PmWideNode>(), node_cap, reinterpret_cast<PmTriRecord*>(d_records),
+    CollapseArgs<P> ca{tris.as<P>(), vals2.as<uint32_t>(), children.as<uint2>(), range.as<uint2>(), ibox.as<GBox>(),
+                    big_nodes.as<PmWideNode>(), node_cap, reinterpret_cast<Rec*>(d_records),
                     counters.as<uint32_t>(), counters.as<uint32_t>() + 1, counters.as<uint32_t>() + 2, max_leaf};
     uint32_t n_in = 1;
     uint2 *qin = q0.as<uint2>(), *qout = q1.as<uint2>();
     for (int level = 0; n_in > 0 && level < 4096; ++level) {
         GBCHK(hipMemsetAsync(counters.as<uint32_t>() + 3, 0, 4, st));
-        hipLaunchKernelGGL(collapse_kernel, dim3((n_in + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, st, ca, qin, n_in, qout,
+        hipLaunchKernelGGL(collapse_kernel<P>, dim3((n_in + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, st, ca, qin, n_in, qout,
                            counters.as<uint32_t>() + 3);
         uint32_t h[4];
         GBCHK(hipMemcpyAsync(h, counters.p, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -398,8 +421,30 @@ int pm_gpu_build_tris(pm_ctx* c, int max_leaf, std::string& err) {
     c->accel.nodes.clear(); c->accel.nodes.shrink_to_fit();
     c->accel.prims.clear(); c->accel.prims.shrink_to_fit();
     c->accel.dev_nodes = n_nodes;
-    c->accel.dev_prim_bytes = n * sizeof(PmTriRecord);
+    c->accel.dev_prim_bytes = n * sizeof(Rec);
     for (int k = 0; k < 3; ++k) { c->accel.bounds.lo[k] = scene.lo[k]; c->accel.bounds.hi[k] = scene.hi[k]; }
     c->accel.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return PM_OK;
+}
+
+// PM_SPLIT_HLBVH entry point of pm_build_accel.  Returns PM_ERR_UNSUPPORTED when the scene does not qualify - spheres, a mix of
+// primitive types, fewer than 4096 primitives - or when the device cannot spare the build's scratch (the caller then uses the
+// host builder).
+int pm_gpu_build_tris(pm_ctx* c, int max_leaf, std::string& err) {
+    const pm::HostScene& sc = c->scene;
+    if (!sc.spheres.empty() || (!sc.tris.empty() && !sc.patches.empty())) return PM_ERR_UNSUPPORTED;
+    if (!sc.tris.empty()) {
+        const size_t n = sc.tris.size();
+        if (n < 4096 || n > 0x3FFFFFFFull / PM_UNITS_TRI) return PM_ERR_UNSUPPORTED;
+        return gpu_build<pm::HostTri>(c, sc.tris.data(), n, max_leaf, err);
+    }
+    const size_t n = sc.patches.size();
+    if (n < 4096 || n > 0x3FFFFFFFull / PM_UNITS_PATCH) return PM_ERR_UNSUPPORTED;
+    std::vector<GBPatch> gp(n);
+    for (size_t i = 0; i < n; ++i) {
+        const pm::HostPatch& p = sc.patches[i];
+        std::memcpy(gp[i].p, p.p, 48);
+        gp[i].prim_id = p.prim_id; gp[i].flags = p.flip_normal ? 1u : 0u; gp[i].bounds = p.bounds;
+    }
+    return gpu_build<GBPatch>(c, gp.data(), n, max_leaf, err);
 }

@@ -67,12 +67,16 @@ struct PathArrays {
 __device__ __forceinline__ float4 with_w(f3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
 struct SceneArrays {
     const PmWideNode* nodes; const uint4* prims;
-    const uint32_t* prim_ref;        // prim id -> type << 30 | index into shade arrays
-    const DShadePatch* patches; const DShadeSphere* spheres;
-    const uint32_t* prim_material; const DMaterial* materials; const DLight* lights; const int* infinite;
+    const uint32_t* prim_ref;        // prim id -> type << 30 | index into shade arrays; NULL in a scene without spheres: then
+                                     // patches[] is indexed by the primitive id itself (shade_ref)
+    const DShadePatch* patches; const DShadeSphere* spheres;     // each record names its material (.mat) and its area light (.flags >> 8)
+    const DMaterial* materials; const DLight* lights; const int* infinite;
     const float* pool;
-    const int* prim_light;           // prim id -> index of the DiffuseAreaLight on it, or -1 (null: the scene has no area light)
+    int area_lights;                 // the scene has DiffuseAreaLights
 };
+__device__ __forceinline__ uint32_t shade_ref(const SceneArrays& sc, uint32_t prim_id) {
+    return sc.prim_ref ? sc.prim_ref[prim_id] : (((uint32_t)PM_PRIM_PATCH << 30) | prim_id);
+}
 
 __device__ __forceinline__ unsigned long long rng_inc_of(const RenderConst& rc, uint32_t slot) {     // rng_start, dimension 0
     const unsigned long long s = (unsigned long long)(rc.s_base + (int)(slot / (uint32_t)rc.npix_pad));
@@ -130,12 +134,12 @@ __global__ __launch_bounds__(RB) void raygen_kernel(RenderConst rc, SceneArrays 
 }
 
 // ------------------------------------------------------------------------------------------ traversal
-template <bool COUNT, bool MIXED>
-__global__ __launch_bounds__(TB) PM_TRAV_ATTR(false, MIXED) void closest_kernel(SceneArrays sc, PathArrays pa, uint32_t g,
+template <bool COUNT, int KIND>
+__global__ __launch_bounds__(TB) PM_TRAV_ATTR(false, KIND) void closest_kernel(SceneArrays sc, PathArrays pa, uint32_t g,
                                                      const uint32_t* __restrict__ count, uint32_t* __restrict__ work, uint32_t refill,
                                                      uint4* __restrict__ defer_list, uint32_t defer_cap, unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
-    __shared__ uint32_t cand[PM_CAND_WORDS(false, COUNT, MIXED) * TB];     // units, then t lower bounds, then the ring of parked leaves
+    __shared__ uint32_t cand[PM_CAND_WORDS(false, COUNT, KIND) * TB];     // units, then t lower bounds, then the ring of parked leaves
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
         const float4 d = pa.rd[g][i];
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR(false, MIXED) void closest_kernel(
     auto commit = [&](uint32_t i, bool found, const HitRec& h) {
         pa.hit[i] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
     };
-    trace_persistent<false, COUNT, MIXED>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB,
+    trace_persistent<false, COUNT, KIND>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB,
                                    defer_list, work + PM_WORK_SLOTS, defer_cap, &tc, fetch, commit);
     if (COUNT) {
         atomicAdd(&counters[1], (unsigned long long)tc.nodes); atomicAdd(&counters[2], (unsigned long long)tc.prims);
@@ -155,12 +159,12 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR(false, MIXED) void closest_kernel(
     }
     if (tc.overflow) atomicAdd(&counters[3], 1ull);
 }
-template <bool COUNT, bool MIXED>
-__global__ __launch_bounds__(TB) PM_TRAV_ATTR(true, MIXED) void shadow_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ count,
+template <bool COUNT, int KIND>
+__global__ __launch_bounds__(TB) PM_TRAV_ATTR(true, KIND) void shadow_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ count,
                                                     uint32_t* __restrict__ work, uint32_t refill, uint4* __restrict__ defer_list, uint32_t defer_cap,
                                                     unsigned long long* __restrict__ counters) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
-    __shared__ uint32_t cand[PM_CAND_WORDS(true, COUNT, MIXED) * TB];     // units, then t lower bounds, then the ring of parked leaves
+    __shared__ uint32_t cand[PM_CAND_WORDS(true, COUNT, KIND) * TB];     // units, then t lower bounds, then the ring of parked leaves
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
         const float4 o = pa.sh_o[i], d = pa.sh_d[i];
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR(true, MIXED) void shadow_kernel(Sc
             pa.L[slot] = L;
         }
     };
-    trace_persistent<true, COUNT, MIXED>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB,
+    trace_persistent<true, COUNT, KIND>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB,
                                   defer_list, work + PM_WORK_SLOTS, defer_cap, &tc, fetch, commit);
     if (COUNT) {
         atomicAdd(&counters[4], (unsigned long long)tc.nodes); atomicAdd(&counters[5], (unsigned long long)tc.prims);
@@ -406,8 +410,8 @@ __device__ __forceinline__ bool sample_light(const RenderConst& rc, const SceneA
         *p_light = p;
     } else {
         ShapeSample ss;
-        const uint32_t ref = sc.prim_ref[lt.prim_id];
-        if (!patch_sample_ctx(sc.patches[ref & 0x3FFFFFFFu], sc.pool, pm, u2, &ss)) return false;
+        const uint32_t ref = shade_ref(sc, lt.prim_id);
+        if (!patch_sample_ctx(sc.patches[ref & 0x3FFFFFFFu], sc.pool, lt.m, lt.m[4] != 0.0f, pm, u2, &ss)) return false;
         const f3 dv = ss.p - pm;
         if (ss.pdf == 0.0f || dot3(dv, dv) == 0.0f) return false;
         *wi = norm3(dv);
@@ -526,14 +530,22 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
             } else if (AREA || depth != rc.max_depth) {
                 // ---- interaction
                 // (the material record is fetched beside the shading record, not behind the interaction's arithmetic)
-                const uint32_t ref = sc.prim_ref[prim_id];
-                const DMaterial mat = sc.materials[sc.prim_material[prim_id]];
+                const uint32_t ref = shade_ref(sc, prim_id);
                 SurfInt si;
-                if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], mk3(ro4.x, ro4.y, ro4.z), rd, hv.y);
-                else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
+                uint32_t mat_id, rec_flags = 0u;
+                if ((ref >> 30) == PM_PRIM_SPHERE) {
+                    const DShadeSphere& ss = sc.spheres[ref & 0x3FFFFFFFu];
+                    mat_id = ss.mat;
+                    si = sphere_interaction(ss, mk3(ro4.x, ro4.y, ro4.z), rd, hv.y);
+                } else {
+                    const DShadePatch& sp = sc.patches[ref & 0x3FFFFFFFu];
+                    mat_id = sp.mat; rec_flags = sp.flags;
+                    si = patch_interaction(sp, hv.z, hv.w, sc.pool);
+                }
+                const DMaterial mat = sc.materials[mat_id];
                 // ---- emitted radiance of an area light on this primitive (simple_path.rs:156-158; AREA instantiation only)
-                if (AREA && sc.prim_light && (!rc.sample_lights || specular)) {
-                    const int li = sc.prim_light[prim_id];
+                if (AREA && (!rc.sample_lights || specular)) {
+                    const int li = (int)(rec_flags >> 8) - 1;
                     if (li >= 0) {
                         const DLight lt = sc.lights[li];
                         if (lt.two_sided || !(dot3(si.n, -rd) < 0.0f)) {
@@ -725,12 +737,20 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
             } else {
                 // ---- interaction (fetching the material record here, beside the shading record, costs this kernel registers
                 // it does not have: 44.4 -> 48.5 ms per C5 frame)
-                const uint32_t ref = sc.prim_ref[prim_id];
-                if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], mk3(ro4.x, ro4.y, ro4.z), rd, hv.y);
-                else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
+                const uint32_t ref = shade_ref(sc, prim_id);
+                uint32_t mat_id, rec_flags = 0u;
+                if ((ref >> 30) == PM_PRIM_SPHERE) {
+                    const DShadeSphere& ss = sc.spheres[ref & 0x3FFFFFFFu];
+                    mat_id = ss.mat;
+                    si = sphere_interaction(ss, mk3(ro4.x, ro4.y, ro4.z), rd, hv.y);
+                } else {
+                    const DShadePatch& sp = sc.patches[ref & 0x3FFFFFFFu];
+                    mat_id = sp.mat; rec_flags = sp.flags;
+                    si = patch_interaction(sp, hv.z, hv.w, sc.pool);
+                }
                 // ---- emitted radiance of an area light on this primitive (simple_path.rs:156-158)
-                if (sc.prim_light && (!rc.sample_lights || specular)) {
-                    const int li = sc.prim_light[prim_id];
+                if (sc.area_lights && (!rc.sample_lights || specular)) {
+                    const int li = (int)(rec_flags >> 8) - 1;
                     if (li >= 0) {
                         const DLight lt = sc.lights[li];
                         if (lt.two_sided || !(dot3(si.n, -rd) < 0.0f)) {
@@ -742,7 +762,7 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                 }
                 if (depth != rc.max_depth) {
                     depth++;
-                    bsdf = make_bsdf<EXT>(sc, pa, si, sc.materials[sc.prim_material[prim_id]], ref, lam, slot, hv.z, hv.w);
+                    bsdf = make_bsdf<EXT>(sc, pa, si, sc.materials[mat_id], ref, lam, slot, hv.z, hv.w);
                     vtx = true;
                     vp = si_p(si);
                     wo = -rd;
@@ -887,11 +907,12 @@ __global__ __launch_bounds__(RB) void shade_rw_kernel(RenderConst rc, SceneArray
             }
         } else if (depth != rc.max_depth) {
             const f3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
-            const uint32_t ref = sc.prim_ref[prim_id];
+            const uint32_t ref = shade_ref(sc, prim_id);
             SurfInt si;
-            if ((ref >> 30) == PM_PRIM_SPHERE) si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], ro, rd, hv.y);
-            else si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool);
-            const Bsdf bsdf = make_bsdf<false>(sc, pa, si, sc.materials[sc.prim_material[prim_id]], ref, lam, slot);
+            uint32_t mat_id;
+            if ((ref >> 30) == PM_PRIM_SPHERE) { mat_id = sc.spheres[ref & 0x3FFFFFFFu].mat; si = sphere_interaction(sc.spheres[ref & 0x3FFFFFFFu], ro, rd, hv.y); }
+            else { mat_id = sc.patches[ref & 0x3FFFFFFFu].mat; si = patch_interaction(sc.patches[ref & 0x3FFFFFFFu], hv.z, hv.w, sc.pool); }
+            const Bsdf bsdf = make_bsdf<false>(sc, pa, si, sc.materials[mat_id], ref, lam, slot);
             const f3 wo = -rd;
             const uint2 r2 = pa.rng[g][i];
             rng.state = ((unsigned long long)r2.y << 32) | r2.x; rng.inc = rng_inc_of(rc, slot);
@@ -1006,14 +1027,14 @@ struct RenderState {
     std::vector<uint32_t> prim_mat;
     std::vector<PmLight> lights; std::vector<std::vector<float>> light_tables;
     bool have_medium = false; PmMedium medium{}; std::vector<float> med_sigma_a, med_sigma_s;
-    int med_off_a = 0, med_off_s = 0; bool have_area_lights = false; int* d_prim_light = nullptr;
+    int med_off_a = 0, med_off_s = 0; bool have_area_lights = false; bool direct_records = false;
     PmCamera cam{}; bool have_cam = false;
     PmFilm film{}; bool have_film = false;
     std::vector<float> sensor, filter_vals;
     // device
     bool scene_dirty = true; uint64_t geom_gen = ~0ull;     // pm_ctx::geom_gen the tables were uploaded for
     float* d_pool = nullptr; DMaterial* d_mats = nullptr; DLight* d_lights = nullptr; int* d_inf = nullptr;
-    uint32_t *d_prim_mat = nullptr, *d_prim_ref = nullptr; DShadePatch* d_patches = nullptr; DShadeSphere* d_spheres = nullptr;
+    uint32_t* d_prim_ref = nullptr; DShadePatch* d_patches = nullptr; DShadeSphere* d_spheres = nullptr;
     float* d_m9 = nullptr;
     int n_inf = 0;
     DFilter dfilter{}; int sensor_off = 0;
@@ -1031,7 +1052,7 @@ void pm_render_state_destroy(pm_ctx* c) {
     if (!r) return;
     for (void* p : r->pa_allocs) (void)hipFree(p);
     for (hipEvent_t e : r->ev_pool) (void)hipEventDestroy(e);
-    void* ptrs[] = {r->d_pool, r->d_mats, r->d_lights, r->d_inf, r->d_prim_mat, r->d_prim_ref, r->d_patches, r->d_spheres, r->d_m9, r->d_film, r->d_prim_light};
+    void* ptrs[] = {r->d_pool, r->d_mats, r->d_lights, r->d_inf, r->d_prim_ref, r->d_patches, r->d_spheres, r->d_m9, r->d_film};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete r;
     c->render = nullptr;
@@ -1272,12 +1293,26 @@ static int upload_scene(pm_ctx* c, RenderState* r) {
         df.marg_func = add_table(mfunc); df.marg_cdf = add_table(mcdf);
     }
     r->dfilter = df;
-    // shading records, by primitive id
-    std::vector<uint32_t> ref(n_prims);
+    // shading records.  Every record names its material and its area light.  In a scene WITHOUT spheres record i belongs to
+    // primitive id i (direct: no prim_ref table on the device); with spheres the two record arrays are reached through prim_ref
+    const bool direct = c->scene.spheres.empty();
+    r->direct_records = direct;
+    std::vector<uint32_t> ref(direct ? 0 : n_prims);
     std::vector<DShadePatch> sp; std::vector<DShadeSphere> ss;
-    sp.reserve(c->scene.patches.size() + c->scene.tris.size());
+    const size_t n_flat = c->scene.patches.size() + c->scene.tris.size();
+    if (direct) sp.resize(n_flat); else sp.reserve(n_flat);
+    auto light_bits = [&](uint32_t prim_id) -> uint32_t {
+        const int li = prim_light.empty() ? -1 : prim_light[prim_id];
+        return li >= 0 ? ((uint32_t)(li + 1) << 8) : 0u;
+    };
+    if (dl.size() >= (1u << 24)) return fail(c, PM_ERR_UNSUPPORTED, "pm_render: more than 2^24 - 1 lights");
+    auto place = [&](uint32_t prim_id, const DShadePatch& d) {
+        if (direct) sp[prim_id] = d;
+        else { ref[prim_id] = ((uint32_t)PM_PRIM_PATCH << 30) | (uint32_t)sp.size(); sp.push_back(d); }
+    };
     for (const auto& p : c->scene.patches) {
-        DShadePatch d{}; std::memcpy(d.p, p.p, 48); d.flags = p.flip_normal ? 1u : 0u;
+        DShadePatch d{}; std::memcpy(d.p, p.p, 48); d.flags = (p.flip_normal ? 1u : 0u) | light_bits(p.prim_id);
+        d.mat = r->prim_mat[p.prim_id];
         if (p.has_normals) {
             d.flags |= 2u; d.nrm_off = (uint32_t)pool.size();
             pool.insert(pool.end(), &p.n[0][0], &p.n[0][0] + 12);
@@ -1286,29 +1321,40 @@ static int upload_scene(pm_ctx* c, RenderState* r) {
             d.flags |= 4u; d.uv_off = (uint32_t)pool.size();
             pool.insert(pool.end(), &p.uv[0][0], &p.uv[0][0] + 8);
         }
-        ref[p.prim_id] = ((uint32_t)PM_PRIM_PATCH << 30) | (uint32_t)sp.size(); sp.push_back(d);
+        place(p.prim_id, d);
     }
     for (const auto& t : c->scene.tris) {
-        DShadePatch d{}; std::memcpy(d.p, t.v, 36); std::memcpy(d.p + 9, t.v[2], 12); d.flags = 0u;
-        ref[t.prim_id] = ((uint32_t)PM_PRIM_PATCH << 30) | (uint32_t)sp.size(); sp.push_back(d);
+        DShadePatch d{}; std::memcpy(d.p, t.v, 36); std::memcpy(d.p + 9, t.v[2], 12); d.flags = light_bits(t.prim_id);
+        d.mat = r->prim_mat[t.prim_id];
+        place(t.prim_id, d);
     }
     for (const auto& s : c->scene.spheres) {
         DShadeSphere d{};
         std::memcpy(d.rfo, s.render_from_object, 48); std::memcpy(d.ofr, s.object_from_render, 48);
         d.radius = s.radius; d.z_min = s.z_min; d.z_max = s.z_max; d.phi_max = s.phi_max; d.th_min = s.theta_z_min; d.th_max = s.theta_z_max;
         d.flags = s.reverse_orientation ? 1u : 0u;
+        d.mat = r->prim_mat[s.prim_id];
         ref[s.prim_id] = ((uint32_t)PM_PRIM_SPHERE << 30) | (uint32_t)ss.size(); ss.push_back(d);
+    }
+    // BilinearPatch::sample's per-patch constants of every area light (pm_shade.hpp patch_area_constants), in DLight.m
+    for (size_t i = 0; i < dl.size(); ++i) {
+        if (dl[i].type != PM_LIGHT_DIFFUSE_AREA) continue;
+        // (the emitter's record: a triangle's holds v0 v1 v2 v2, the degenerate patch it is; spheres were rejected above)
+        const float* q = direct ? sp[dl[i].prim_id].p : sp[ref[dl[i].prim_id] & 0x3FFFFFFFu].p;
+        float w4[4]; bool rect = false;
+        patch_area_constants(mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), mk3(q[6], q[7], q[8]), mk3(q[9], q[10], q[11]), w4, &rect);
+        std::memset(dl[i].m, 0, sizeof(dl[i].m));
+        for (int k = 0; k < 4; ++k) dl[i].m[k] = w4[k];
+        dl[i].m[4] = rect ? 1.0f : 0.0f;
     }
     int rc;
     if ((rc = upload(c, &r->d_pool, pool))) return rc;
     if ((rc = upload(c, &r->d_mats, dm))) return rc;
     if ((rc = upload(c, &r->d_lights, dl))) return rc;
     if ((rc = upload(c, &r->d_inf, inf))) return rc;
-    if ((rc = upload(c, &r->d_prim_mat, r->prim_mat))) return rc;
     if ((rc = upload(c, &r->d_prim_ref, ref))) return rc;
     if ((rc = upload(c, &r->d_patches, sp))) return rc;
     if ((rc = upload(c, &r->d_spheres, ss))) return rc;
-    if ((rc = upload(c, &r->d_prim_light, prim_light))) return rc;
     r->scene_dirty = false;
     r->geom_gen = c->geom_gen;
     return PM_OK;
@@ -1382,7 +1428,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     if ((rcode = ensure_paths(c, r, max_paths, p->max_depth, random_walk))) return rcode;
     if ((rcode = ensure_defer(c, max_paths))) return rcode;
     const bool has_spheres = !c->scene.spheres.empty();
-    const bool mixed = has_spheres || !c->scene.patches.empty();      // tree-walk kernel variant
+    const int kind = pm_walk_kind(c);      // tree-walk kernel variant
 
     RenderConst rc{};
     std::memcpy(rc.cfr, r->cam.camera_from_raster, 64); std::memcpy(rc.rfc, r->cam.render_from_camera, 48);
@@ -1409,8 +1455,8 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     }
     rc.win_x0 = x0; rc.win_y0 = y0; rc.win_w = W; rc.win_h = H; rc.tiles_x = tiles_x; rc.npix_pad = (int)npix_pad;
     rc.film_x0 = pb[0]; rc.film_y0 = pb[1]; rc.film_w = pb[2] - pb[0];
-    SceneArrays sa{c->d_nodes, c->d_prims, r->d_prim_ref, r->d_patches, r->d_spheres, r->d_prim_mat, r->d_mats, r->d_lights, r->d_inf, r->d_pool,
-                   r->have_area_lights ? r->d_prim_light : nullptr};
+    SceneArrays sa{c->d_nodes, c->d_prims, r->direct_records ? nullptr : r->d_prim_ref, r->d_patches, r->d_spheres, r->d_mats, r->d_lights,
+                   r->d_inf, r->d_pool, r->have_area_lights ? 1 : 0};
     PathArrays& pa = r->pa;
     const int nb = p->max_depth + 2;
     std::vector<uint32_t> hcounts(2 * (size_t)nb * PM_CNT_STRIDE);
@@ -1458,8 +1504,8 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
                                           : (fpatch ? closest_flat_kernel<false, true> : closest_flat_kernel<false, false>);
                 hipLaunchKernelGGL(kernel, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, gen, cnt_in, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, c->d_slow, c->d_counters);
             } else {
-                auto kernel = c->counting ? (mixed ? closest_kernel<true, true> : closest_kernel<true, false>)
-                                          : (mixed ? closest_kernel<false, true> : closest_kernel<false, false>);
+                auto kernel = c->counting ? (kind == PM_WALK_MIXED ? closest_kernel<true, PM_WALK_MIXED> : kind == PM_WALK_PATCH ? closest_kernel<true, PM_WALK_PATCH> : closest_kernel<true, PM_WALK_TRI>)
+                                          : (kind == PM_WALK_MIXED ? closest_kernel<false, PM_WALK_MIXED> : kind == PM_WALK_PATCH ? closest_kernel<false, PM_WALK_PATCH> : closest_kernel<false, PM_WALK_TRI>);
                 hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, gen, cnt_in, c->d_work + wslot, c->refill, c->d_defer, (uint32_t)c->defer_cap, c->d_counters);
             }
             if (has_spheres || flat) {     // second pass: dense exact tests of what was deferred (timed with the closest-hit class)
@@ -1471,7 +1517,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
                 // the same queue through the counting walk (the hits it leaves in pa.hit are the ones the pass goes on with)
                 HIPCHK(c, hipMemcpyAsync(verify_hits, pa.hit, (size_t)npaths * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
                 if (wslot + 2 > PM_WORK_SLOTS) { HIPCHK(c, hipMemsetAsync(c->d_work, 0, 3 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream)); wslot = 0; }
-                auto kernel = mixed ? closest_kernel<true, true> : closest_kernel<true, false>;
+                auto kernel = kind == PM_WALK_MIXED ? closest_kernel<true, PM_WALK_MIXED> : kind == PM_WALK_PATCH ? closest_kernel<true, PM_WALK_PATCH> : closest_kernel<true, PM_WALK_TRI>;
                 hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, gen, cnt_in, c->d_work + wslot, c->refill, c->d_defer, (uint32_t)c->defer_cap, c->d_counters);
                 ++wslot;
                 hipLaunchKernelGGL(verify_hits_kernel, gr, dim3(RB), 0, c->stream, pa, gen, cnt_in, verify_hits, (uint32_t)b, verify_bad, verify_recs, 64u);
@@ -1488,8 +1534,8 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
                                               : (fpatch ? shadow_flat_kernel<false, true> : shadow_flat_kernel<false, false>);
                     hipLaunchKernelGGL(kernel, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, cnt_sh, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, c->d_slow, c->d_counters);
                 } else {
-                    auto kernel = c->counting ? (mixed ? shadow_kernel<true, true> : shadow_kernel<true, false>)
-                                              : (mixed ? shadow_kernel<false, true> : shadow_kernel<false, false>);
+                    auto kernel = c->counting ? (kind == PM_WALK_MIXED ? shadow_kernel<true, PM_WALK_MIXED> : kind == PM_WALK_PATCH ? shadow_kernel<true, PM_WALK_PATCH> : shadow_kernel<true, PM_WALK_TRI>)
+                                              : (kind == PM_WALK_MIXED ? shadow_kernel<false, PM_WALK_MIXED> : kind == PM_WALK_PATCH ? shadow_kernel<false, PM_WALK_PATCH> : shadow_kernel<false, PM_WALK_TRI>);
                     hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_work + wslot, c->refill, c->d_defer, (uint32_t)c->defer_cap, c->d_counters);
                 }
                 if (has_spheres || flat) {

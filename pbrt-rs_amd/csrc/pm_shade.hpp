@@ -82,7 +82,7 @@ PMD void cr_exp_neg4(const float* k, float x, float* out) {
 PMD float clampf(float x, float lo, float hi) { float r = x; if (r < lo) r = lo; if (r > hi) r = hi; return r; }
 PMD float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 PMD float safe_sqrtf(float x) { return sqrtf(fmaxf(x, 0.0f)); }
-PMD f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+PMHD f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
 PMD f3 face_fwd(f3 n, f3 v) { return (__float_as_uint(dot3(n, v)) >> 31) ? -n : n; }
 
 // ---------------------------------------------------------------------------------------- rng
@@ -121,6 +121,9 @@ PMD float rng_uniform(Rng* r) {
 // ---------------------------------------------------------------------------------------- spectra
 struct DSpectrum { int kind; float a, b, c, d; int table; };   // table: offset into the float pool
 struct DMaterial { int type; DSpectrum spec; float ur, vr; int remap; int texture; float su, sv, du, dv; DSpectrum spec2; };
+// DIFFUSE_AREA lights do not use m: m[0..3] hold the four corner-area weights of BilinearPatch::sample's bilinear warp and
+// m[4] != 0 says the patch is a rectangle (patch_area_constants below: computed once per light at upload instead of once per
+// light sample - ~350 instructions, half of them f64, of every path vertex of an area-lit scene)
 struct DLight { int type; float scale; float m[12]; int table; uint32_t prim_id; int two_sided; };
 
 PMD float dense_at(const float* __restrict__ pool, int table, float lambda) {
@@ -274,8 +277,12 @@ PMD float sample_tent(float u, float r) {
 
 // ---------------------------------------------------------------------------------------- render constants
 struct DFilter { int kind; float rx, ry; int nx, ny; int vals, cond_cdf, cond_int, marg_func, marg_cdf; float marg_int; };
-struct DShadePatch { float p[12]; uint32_t flags; uint32_t nrm_off; uint32_t uv_off; uint32_t pad; };     // 64 B; flags bit 0 flip normal, bit 1 vertex normals (12 floats at pool[nrm_off]), bit 2 vertex uv (8 floats at pool[uv_off]: uv00 uv10 uv01 uv11)
-struct DShadeSphere { float rfo[12]; float ofr[12]; float radius, z_min, z_max, phi_max, th_min, th_max; uint32_t flags; uint32_t pad; };  // 128 B
+// 64 B; flags bit 0 flip normal, bit 1 vertex normals (12 floats at pool[nrm_off]), bit 2 vertex uv (8 floats at pool[uv_off]:
+// uv00 uv10 uv01 uv11), bits 8.. = 1 + index of the DiffuseAreaLight on this primitive (0: none); mat = material id.  Round 3:
+// material and light ride in the record, and in a scene without spheres record i belongs to primitive id i - so a path vertex
+// goes hit -> record -> material where it went hit -> (prim_ref, prim_material, prim_light) -> (record, material)
+struct DShadePatch { float p[12]; uint32_t flags; uint32_t nrm_off; uint32_t uv_off; uint32_t mat; };
+struct DShadeSphere { float rfo[12]; float ofr[12]; float radius, z_min, z_max, phi_max, th_min, th_max; uint32_t flags; uint32_t mat; };  // 128 B
 
 struct RenderConst {
     float cfr[16];            // camera_from_raster
@@ -499,9 +506,9 @@ PMD f3 sample_henyey_greenstein(f3 wo, float g, f2 u, float* pdf) {
     return (st * cp) * x + (st * sp) * y + ct * wo;
 }
 // shapes/bilinear_patch.rs:739-773
-PMD bool f3_eq(f3 a, f3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
-PMD float dist2(f3 a, f3 b) { const f3 d = a - b; return dot3(d, d); }
-PMD bool patch_is_rectangle(f3 p00, f3 p10, f3 p01, f3 p11) {
+PMHD bool f3_eq(f3 a, f3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+PMHD float dist2(f3 a, f3 b) { const f3 d = a - b; return dot3(d, d); }
+PMHD bool patch_is_rectangle(f3 p00, f3 p10, f3 p01, f3 p11) {
     if (f3_eq(p00, p01) || f3_eq(p01, p11) || f3_eq(p11, p10) || f3_eq(p10, p00)) return false;
     const f3 n = norm3(cross3(p10 - p00, p01 - p00));
     if (fabsf(dot3(norm3(p11 - p00), n)) > 1e-5f) return false;
@@ -510,18 +517,22 @@ PMD bool patch_is_rectangle(f3 p00, f3 p10, f3 p01, f3 p11) {
     if (fabsf(d0 - d0) / d0 > 1e-4f || fabsf(d1 - d0) / d0 > 1e-4f || fabsf(d2 - d0) / d0 > 1e-4f || fabsf(d3 - d0) / d0 > 1e-4f) return false;
     return true;
 }
+// what BilinearPatch::sample needs of the patch alone (bilinear_patch.rs:268-283): is it a rectangle, else the corner areas
+PMHD void patch_area_constants(f3 p00, f3 p10, f3 p01, f3 p11, float* w4, bool* rect) {
+    *rect = patch_is_rectangle(p00, p10, p01, p11);
+    w4[0] = len3(cross3(p10 - p00, p01 - p00)); w4[1] = len3(cross3(p10 - p00, p11 - p10));
+    w4[2] = len3(cross3(p01 - p00, p11 - p01)); w4[3] = len3(cross3(p11 - p10, p11 - p01));
+}
 struct ShapeSample { f3 p; f3 n; float pdf; };
 // BilinearPatch::sample + the area-sampling branch of sample_with_context (bilinear_patch.rs:260-352); the spherical-
 // rectangle branch is todo!() upstream (sampling/routines.rs:307-327), so every patch is sampled by area
-PMD bool patch_sample_ctx(const DShadePatch& sp, const float* __restrict__ pool, f3 ref_p, f2 u, ShapeSample* out) {
+PMD bool patch_sample_ctx(const DShadePatch& sp, const float* __restrict__ pool, const float* w, bool rect, f3 ref_p, f2 u,
+                          ShapeSample* out) {
     const f3 p00 = mk3(sp.p[0], sp.p[1], sp.p[2]), p10 = mk3(sp.p[3], sp.p[4], sp.p[5]);
     const f3 p01 = mk3(sp.p[6], sp.p[7], sp.p[8]), p11 = mk3(sp.p[9], sp.p[10], sp.p[11]);
     f2 uv; float pdf;
-    if (!patch_is_rectangle(p00, p10, p01, p11)) {
-        const float w[4] = {len3(cross3(p10 - p00, p01 - p00)), len3(cross3(p10 - p00, p11 - p10)),
-                            len3(cross3(p01 - p00, p11 - p01)), len3(cross3(p11 - p10, p11 - p01))};
-        uv = sample_bilinear(u, w); pdf = bilinear_pdf(uv, w);
-    } else { uv = u; pdf = 1.0f; }
+    if (!rect) { uv = sample_bilinear(u, w); pdf = bilinear_pdf(uv, w); }     // (w, rect: patch_area_constants, once per light)
+    else { uv = u; pdf = 1.0f; }
     const f3 pu0 = lerp3(p00, p01, uv.y), pu1 = lerp3(p10, p11, uv.y);
     const f3 pt = lerp3(pu0, pu1, uv.x);
     const f3 dpdu = pu1 - pu0;

@@ -90,6 +90,10 @@ def render_distributed(integrator, mode="samples", group=None):
     integrator.film(out=film)
     if world > 1:
         film = allreduce_film(film, group) if mode == "samples" else allgather_rows(film, integrator.bounds, group)
+        # the collective and the copies that assemble the bands run on torch's streams; the library reads `film` on its own
+        # (non-blocking) stream, which does not order against them: wait before handing the tensor over.  (Found in round 3 with
+        # four ranks on one card: the tail of the assembled film was still being written when film_add read it.)
+        torch.cuda.current_stream().synchronize() if film.is_cuda else None
         integrator.clear()
         integrator.film_add(film)
     return film

@@ -25,6 +25,44 @@ def blob_mesh(n_blobs=1024, tris_per_blob=1024, seed=1, blob_sigma=0.06, tri_siz
     return pos, idx
 
 
+def blob_patch_mesh(n_blobs=1024, per_blob=1024, seed=1, blob_sigma=0.06, size=0.012, warp=0.35):
+    """C3's geometry with the reference's own primitive: `n_blobs` clusters of `per_blob` small NON-PLANAR bilinear patches
+    (blob centres uniform in [-1,1]^3, patch centres normal(0, blob_sigma) about them, two random edge vectors of at most `size`
+    per component, and the fourth corner pushed off the parallelogram's plane by `warp` of the edge lengths).
+    Returns (positions float32 [4P, 3], indices uint32 [P, 4] in p00 p10 p01 p11 order)."""
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform(-1.0, 1.0, size=(n_blobs, 1, 3)).astype(np.float32)
+    c = centres + rng.normal(0.0, blob_sigma, size=(n_blobs, per_blob, 3)).astype(np.float32)
+    e1 = rng.uniform(-size, size, size=(n_blobs, per_blob, 3)).astype(np.float32)
+    e2 = rng.uniform(-size, size, size=(n_blobs, per_blob, 3)).astype(np.float32)
+    w = (rng.uniform(-size, size, size=(n_blobs, per_blob, 3)) * warp).astype(np.float32)
+    p00 = c - 0.5 * e1 - 0.5 * e2
+    quad = np.stack([p00, p00 + e1, p00 + e2, p00 + e1 + e2 + w], axis=2)          # [B, P, 4, 3]
+    pos = np.ascontiguousarray(quad.reshape(-1, 3), dtype=np.float32)
+    idx = np.arange(pos.shape[0], dtype=np.uint32).reshape(-1, 4)
+    return pos, idx
+
+
+def terrain_patch_mesh(grid=1024, seed=7, tilt_deg=55.0, roughness=0.002):
+    """A BilinearPatchMesh at scale - the reference's only mesh primitive (shapes/bilinear_patch.rs:615-707): a grid x grid
+    heightfield of quads over [-1,1]^2 with SHARED vertices ((grid+1)^2 of them), rolling hills plus per-vertex noise so that
+    every patch is non-planar, tilted by `tilt_deg` about the x axis so that rays from (0,0,-4) meet it at a slant.
+    Returns (positions float32 [(grid+1)^2, 3], indices uint32 [grid^2, 4] in p00 p10 p01 p11 order)."""
+    rng = np.random.default_rng(seed)
+    xs = np.linspace(-1.0, 1.0, grid + 1, dtype=np.float64)
+    X, Y = np.meshgrid(xs, xs, indexing="xy")
+    Z = 0.12 * np.sin(3.1 * X + 0.4) * np.cos(2.6 * Y - 0.3) + 0.04 * np.sin(11.0 * X) * np.sin(13.0 * Y)
+    Z += rng.normal(0.0, roughness, size=Z.shape)
+    a = np.radians(tilt_deg)
+    y2 = Y * np.cos(a) - Z * np.sin(a)
+    z2 = Y * np.sin(a) + Z * np.cos(a)
+    pos = np.ascontiguousarray(np.stack([X.reshape(-1), y2.reshape(-1), z2.reshape(-1)], axis=1), dtype=np.float32)
+    j, i = np.meshgrid(np.arange(grid), np.arange(grid), indexing="ij")
+    a00 = (j * (grid + 1) + i).reshape(-1)
+    idx = np.ascontiguousarray(np.stack([a00, a00 + 1, a00 + grid + 1, a00 + grid + 2], axis=1), dtype=np.uint32)
+    return pos, idx
+
+
 def _tile_order(width, height, tile=8):
     """pixel (x, y) arrays in row-major order of tile x tile tiles, row-major inside a tile."""
     assert width % tile == 0 and height % tile == 0

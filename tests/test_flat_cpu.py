@@ -112,11 +112,64 @@ def test_flat_sweep_of_patches_equals_reference(pm, ora, seed):
     assert (~same).sum() <= 4                                   # exact-t ties
     assert np.array_equal(flat["t"].view(np.uint32), ref["t"].view(np.uint32))
     assert np.array_equal(flat["u"][same].view(np.uint32), ref["u"][same].view(np.uint32))
-    # the box pre-filter does its job: far fewer exact tests than (ray, patch) pairs, and what it lets through includes every hit
-    assert fc["exact_tests"] < 0.35 * fc["prims_tested"]
+    # the confirm path of the box pre-filter (every rejected patch goes through the reference arithmetic as well in a counting
+    # walk): no rejection hid a hit
+    assert fc["fallback_walks"] == 0
     occ, _ = ora.wide_trace(nb, pb, rays, any_hit=True, flat=True)
     occ_ref, _ = sc.intersect_p(rays)
     assert np.array_equal(occ.astype(bool), occ_ref.astype(bool))
+
+
+@pytest.mark.parametrize("offset,scale", [(0.0, 1.0), (900.0, 1.0), (0.0, 1e-3), (5e4, 40.0)])
+def test_patch_prefilter_has_no_false_rejects_on_grazing_and_far_patches(pm, ora, offset, scale):
+    """the pad of patch_prefilter was argued, then fuzzed on one 28-patch scene near the origin.  Here: patches far
+    from the origin (coordinates ~ 900, ~ 5e4: the pad and the exact test's epsilon scale with them) and tiny ones, and rays that
+    GRAZE them - aimed at points of the surface along directions within a fraction of a degree of the tangent plane, and along
+    the patch edges.  The counting walk's confirm path puts every rejected patch through the reference arithmetic; a hit it hid
+    would be counted in fallback_walks, and the hits must equal the reference traversal's."""
+    import helpers
+    rng = np.random.default_rng(int(offset) + int(scale * 1000) + 5)
+    base = rng.uniform(-3, 3, size=(24, 1, 3))
+    e1 = rng.normal(size=(24, 3)); e2 = rng.normal(size=(24, 3))
+    e1 /= np.linalg.norm(e1, axis=1, keepdims=True); e2 -= (e2 * e1).sum(1, keepdims=True) * e1
+    e2 /= np.linalg.norm(e2, axis=1, keepdims=True)
+    n = np.cross(e1, e2)
+    corners = np.stack([base[:, 0], base[:, 0] + e1, base[:, 0] + e2, base[:, 0] + e1 + e2 + 0.3 * n * rng.uniform(-1, 1, (24, 1))], axis=1)
+    quads = ((corners * scale) + offset).astype(np.float32)
+    pos = quads.reshape(-1, 3)
+    idx = np.arange(len(pos), dtype=np.uint32).reshape(-1, 4)
+    prims = [pm.BilinearPatchMesh(pos, idx)]
+    agg = pm.GpuAggregate(prims, device_id=-1)
+    assert agg.info.flat_prims == 24
+    m = 60_000
+    k = rng.integers(0, 24, m)
+    q = quads[k].astype(np.float64)
+    u = rng.random(m); v = rng.random(m)
+    edge = rng.random(m) < 0.3
+    u = np.where(edge, np.round(u), u)
+    target = ((1 - u) * (1 - v))[:, None] * q[:, 0] + (u * (1 - v))[:, None] * q[:, 1] + ((1 - u) * v)[:, None] * q[:, 2] + (u * v)[:, None] * q[:, 3]
+    tang = (q[:, 1] - q[:, 0]) * rng.normal(size=(m, 1)) + (q[:, 2] - q[:, 0]) * rng.normal(size=(m, 1))
+    tang /= np.linalg.norm(tang, axis=1, keepdims=True)
+    nrm = np.cross(q[:, 1] - q[:, 0], q[:, 2] - q[:, 0]); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    slope = 10.0 ** rng.uniform(-6, -1, (m, 1)) * rng.choice([-1.0, 1.0], (m, 1))          # grazing angle: 1e-6 .. 0.1 rad
+    d = tang + slope * nrm
+    dist = scale * rng.uniform(0.5, 30.0, (m, 1))
+    rays = np.zeros(m, dtype=pm.RAY_DTYPE)
+    rays["o"] = (target - d * dist).astype(np.float32)
+    rays["d"] = (d * rng.uniform(0.3, 3.0, (m, 1))).astype(np.float32)
+    rays["tmax"] = np.inf
+
+    class SD:
+        pass
+    sd = SD()
+    sd.prims = prims
+    sc = helpers.oracle_scene_from(sd, ora)
+    ref, _ = sc.intersect(rays)
+    flat, fc = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays, flat=True)
+    assert (ref["prim_id"] != 0xFFFFFFFF).mean() > 0.2
+    assert fc["fallback_walks"] == 0, f"{fc['fallback_walks']} rays had a patch rejected by the pre-filter that the reference arithmetic hits"
+    assert np.array_equal(flat["t"].view(np.uint32), ref["t"].view(np.uint32))
+    assert (flat["prim_id"] != ref["prim_id"]).sum() <= 4
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
