@@ -274,6 +274,108 @@ void ora_wide_wave_model_persistent(const void* nodes, const void* prims, const 
     for (int k = 0; k < 6; ++k) out6[k] = a[k];
 }
 
+// Model of a WAVE-PACKET walk (round 3 experiment): the 64 consecutive rays of a wave walk the tree
+// TOGETHER - one wave-uniform stack of (node, lane mask) entries, the node read once, every lane of the mask running the slab
+// test of the 8 children, a child entered when ANY lane hits it (the ballot), leaf triangles pre-filtered by the lanes that hit
+// the leaf's box, children ordered by the octant of the wave's first ray.  Culling per lane as in walk() (certain hits of the
+// triangle pre-filter shorten tcull).  Triangle-only trees.  out8 = {waves, packet node steps (the union of the lanes' node
+// visits), packet prim trips, lane participations in node steps, lane prim tests, waves whose rays span more than one octant,
+// deepest stack, packet node steps in which fewer than 16 lanes take part}.  Analysis tool only.
+void ora_wide_packet_model(const void* nodes_, const void* prims_, const OraRay* rays, uint64_t n, uint64_t* out8, int nthreads) {
+    const WNode* nodes = reinterpret_cast<const WNode*>(nodes_);
+    const uint8_t* prims = reinterpret_cast<const uint8_t*>(prims_);
+    const uint64_t nw = (n + 63) / 64;
+    std::vector<std::array<uint64_t, 8>> acc(std::max(1, nthreads), std::array<uint64_t, 8>{0, 0, 0, 0, 0, 0, 0, 0});
+    parallel_chunks(nw, nthreads, [&](uint64_t b, uint64_t e, int tid) {
+        auto& a = acc[tid];
+        struct LaneS { V3 ro, rd; float inv[3]; bool ng[3]; float R, D, tcull; bool live; };
+        const float widen = 1.0f + 2.0f * gamma_n(3);
+        const float MARGIN = 2.384185791015625e-07f;
+        auto rcp = [](float d) { return std::fabs(d) < 1e-18f ? std::copysign(1e18f, d) : 1.0f / d; };
+        std::vector<std::pair<uint32_t, uint64_t>> stack;
+        for (uint64_t w = b; w < e; ++w) {
+            LaneS L[64];
+            uint64_t live = 0; uint32_t poct = 0; bool have = false, mixed = false;
+            for (int l = 0; l < 64; ++l) {
+                uint64_t i = w * 64 + l;
+                L[l].live = false;
+                if (i >= n) continue;
+                const OraRay& r = rays[i];
+                L[l].ro = V3(r.o[0], r.o[1], r.o[2]); L[l].rd = V3(r.d[0], r.d[1], r.d[2]);
+                const float d3[3] = {r.d[0], r.d[1], r.d[2]};
+                uint32_t oct = 0;
+                for (int k = 0; k < 3; ++k) { L[l].inv[k] = rcp(d3[k]); L[l].ng[k] = L[l].inv[k] < 0; oct |= L[l].ng[k] ? 1u << k : 0u; }
+                L[l].R = WideWalker::maxabs(L[l].ro); L[l].D = WideWalker::maxabs(L[l].rd); L[l].tcull = r.tmax; L[l].live = true;
+                live |= 1ull << l;
+                if (!have) { poct = oct; have = true; } else if (oct != poct) mixed = true;
+            }
+            a[0]++; if (mixed) a[5]++;
+            stack.clear();
+            if (live) stack.emplace_back(0u, live);
+            while (!stack.empty()) {
+                a[6] = std::max<uint64_t>(a[6], stack.size());
+                auto [nidx, mask] = stack.back(); stack.pop_back();
+                const WNode& nd = nodes[nidx];
+                a[1]++; a[3] += (uint64_t)__builtin_popcountll(mask);
+                if (__builtin_popcountll(mask) < 16) a[7]++;
+                uint64_t child_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int l = 0; l < 64; ++l) {
+                    if (!(mask >> l & 1)) continue;
+                    const LaneS& q = L[l];
+                    const float o3[3] = {q.ro.x, q.ro.y, q.ro.z};
+                    float si[3], an[3], af[3], sf[3];
+                    for (int k = 0; k < 3; ++k) {
+                        si[k] = u2f((uint32_t)nd.e[k] << 23) * q.inv[k];
+                        float ad = (nd.o[k] - o3[k]) * q.inv[k];
+                        float m = MARGIN * std::fmaf(256.0f, std::fabs(si[k]), std::fabs(ad));
+                        an[k] = ad - m; af[k] = (ad + m) * widen; sf[k] = si[k] * widen;
+                    }
+                    for (int s = 0; s < 8; ++s) {
+                        float tn[3], tf[3];
+                        for (int k = 0; k < 3; ++k) {
+                            float qn = (float)(q.ng[k] ? nd.qhi[k][s] : nd.qlo[k][s]), qf = (float)(q.ng[k] ? nd.qlo[k][s] : nd.qhi[k][s]);
+                            tn[k] = std::fmaf(qn, si[k], an[k]);
+                            tf[k] = std::fmaf(qf, sf[k], af[k]);
+                        }
+                        float nn = rmax(rmax(tn[0], tn[1]), rmax(tn[2], 0.0f));
+                        float ff = rmin(rmin(tf[0], tf[1]), rmin(tf[2], q.tcull));
+                        if (nn <= ff) child_mask[s] |= 1ull << l;
+                    }
+                }
+                const uint32_t pbase = nd.prim_base & 0x3FFFFFFFu;
+                // leaves of this node first (as the kernel does), nearest first by the packet's octant
+                for (uint32_t k = 0; k < 8; ++k) {
+                    uint32_t s = k ^ poct;
+                    if ((nd.imask >> s & 1) || !child_mask[s]) continue;
+                    uint32_t cnt = nd.meta[s] >> 5, off = nd.meta[s] & 31u;
+                    for (uint32_t j = 0; j < cnt; ++j) {
+                        a[2]++;
+                        const float* f = reinterpret_cast<const float*>(prims + (size_t)(pbase + (off + j) * 3) * 16);
+                        for (int l = 0; l < 64; ++l) {
+                            if (!(child_mask[s] >> l & 1)) continue;
+                            a[4]++;
+                            float th, tl;
+                            int cls = WideWalker::tri_prefilter(L[l].ro, L[l].rd, L[l].R, L[l].D, V3(f[0], f[1], f[2]), V3(f[3], f[4], f[5]),
+                                                               V3(f[6], f[7], f[8]), L[l].tcull, &th, &tl);
+                            if (cls == 2) L[l].tcull = th;
+                        }
+                    }
+                }
+                for (int k = 7; k >= 0; --k) {         // farthest pushed first
+                    uint32_t s = (uint32_t)k ^ poct;
+                    if (!(nd.imask >> s & 1) || !child_mask[s]) continue;
+                    uint32_t cidx = nd.child_base + (uint32_t)__builtin_popcount(nd.imask & ((1u << s) - 1u));
+                    stack.emplace_back(cidx, child_mask[s]);
+                }
+            }
+        }
+    });
+    for (int k = 0; k < 8; ++k) {
+        out8[k] = 0;
+        for (auto& a : acc) { if (k == 6) out8[k] = std::max(out8[k], a[k]); else out8[k] += a[k]; }
+    }
+}
+
 // ---- Integrate::render() on the CPU, from the flattened scene (same struct layouts as include/pbrt_mi355.h) ----
 struct OraRenderer {
     Renderer r;

@@ -846,6 +846,8 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                 const uint32_t qny[2] = {ngy ? n4.x : n2.z, ngy ? n4.y : n2.w}, qfy[2] = {ngy ? n2.z : n4.x, ngy ? n2.w : n4.y};
                 const uint32_t qnz[2] = {ngz ? n4.z : n3.x, ngz ? n4.w : n3.y}, qfz[2] = {ngz ? n3.x : n4.z, ngz ? n3.y : n4.w};
                 uint32_t hits = 0;
+                // (two children per v_pk_fma_f32 - the same IEEE fma per component - was measured in round 3: 5 % SLOWER on C3,
+                // 2.5 % on the C4 closest class, profiles/r03/ab_pk_slab.log; packed f32 has no higher rate on this chip)
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     const int w = s >> 2, kk = s & 3;

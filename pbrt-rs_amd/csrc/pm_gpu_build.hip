@@ -448,3 +448,10 @@ int pm_gpu_build_tris(pm_ctx* c, int max_leaf, std::string& err) {
     }
     return gpu_build<GBPatch>(c, gp.data(), n, max_leaf, err);
 }
+
+// Radix sort of (key, value) pairs on `st` (the ray-reordering experiment of pm_render.hip, PBRT_MI355_REORDER): kept here because
+// this file already pays for the hipcub headers.  tmp == nullptr: size query.
+int pm_sort_pairs_u32(hipStream_t st, void* tmp, size_t* tmp_bytes, const uint32_t* k_in, uint32_t* k_out, const uint32_t* v_in,
+                      uint32_t* v_out, uint32_t n, int end_bit) {
+    return (int)hipcub::DeviceRadixSort::SortPairs(tmp, *tmp_bytes, k_in, k_out, v_in, v_out, (int)n, 0, end_bit, st);
+}

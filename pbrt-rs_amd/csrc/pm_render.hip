@@ -137,11 +137,15 @@ __global__ __launch_bounds__(RB) void raygen_kernel(RenderConst rc, SceneArrays 
 template <bool COUNT, int KIND>
 __global__ __launch_bounds__(TB) PM_TRAV_ATTR(false, KIND) void closest_kernel(SceneArrays sc, PathArrays pa, uint32_t g,
                                                      const uint32_t* __restrict__ count, uint32_t* __restrict__ work, uint32_t refill,
-                                                     uint4* __restrict__ defer_list, uint32_t defer_cap, unsigned long long* __restrict__ counters) {
+                                                     uint4* __restrict__ defer_list, uint32_t defer_cap, unsigned long long* __restrict__ counters,
+                                                     const uint32_t* __restrict__ perm) {
     __shared__ uint2 stack[PM_LDS_STACK * TB];
     __shared__ uint32_t cand[PM_CAND_WORDS(false, COUNT, KIND) * TB];     // units, then t lower bounds, then the ring of parked leaves
     TravCounters tc = {0u, 0u, 0u, 0u, 0u};
+    // perm != NULL (PBRT_MI355_REORDER): the work counter hands out positions in a sorted order of the queue, perm[position] is
+    // the queue entry; the hit goes back to the entry, so nothing downstream sees the order
     auto fetch = [&](uint32_t i, Ray* ray) -> bool {
+        if (perm) i = perm[i];
         const float4 d = pa.rd[g][i];
         if (__float_as_uint(d.w) == PM_DEAD) return false;          // dead entry (raygen)
         const float4 o = pa.ro[g][i];
@@ -149,6 +153,7 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR(false, KIND) void closest_kernel(S
         return true;
     };
     auto commit = [&](uint32_t i, bool found, const HitRec& h) {
+        if (perm) i = perm[i];
         pa.hit[i] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
     };
     trace_persistent<false, COUNT, KIND>(sc.nodes, sc.prims, *count, work, refill, stack + threadIdx.x, cand + threadIdx.x, TB,
@@ -159,6 +164,31 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR(false, KIND) void closest_kernel(S
     }
     if (tc.overflow) atomicAdd(&counters[3], 1ull);
 }
+// PBRT_MI355_REORDER experiment: sort key of queue entry i = Morton code of the ray origin (bits per axis)
+// and the direction's octant.  Entries past the queue's end and dead entries sort last.
+__device__ __forceinline__ uint32_t spread3(uint32_t x) {       // 10 bits -> every third bit
+    x &= 0x3FFu; x = (x | (x << 16)) & 0x030000FFu; x = (x | (x << 8)) & 0x0300F00Fu; x = (x | (x << 4)) & 0x030C30C3u; x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+__global__ __launch_bounds__(RB) void reorder_key_kernel(PathArrays pa, uint32_t g, uint32_t n, f3 lo, f3 scale, int bits, int oct_high,
+                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t i = blockIdx.x * RB + threadIdx.x;
+    if (i >= n) return;
+    const float4 d = pa.rd[g][i], o = pa.ro[g][i];
+    uint32_t key = 0xFFFFFFFFu >> (32 - (3 * bits + 3));
+    if (__float_as_uint(d.w) != PM_DEAD) {
+        const float q = (float)((1u << bits) - 1u);
+        const uint32_t x = (uint32_t)fminf(fmaxf((o.x - lo.x) * scale.x, 0.0f), q), y = (uint32_t)fminf(fmaxf((o.y - lo.y) * scale.y, 0.0f), q),
+                       z = (uint32_t)fminf(fmaxf((o.z - lo.z) * scale.z, 0.0f), q);
+        const uint32_t m = spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
+        const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+        key = oct_high ? ((oct << (3 * bits)) | m) : ((m << 3) | oct);
+    }
+    keys[i] = key; vals[i] = i;
+}
+int pm_sort_pairs_u32(hipStream_t st, void* tmp, size_t* tmp_bytes, const uint32_t* k_in, uint32_t* k_out, const uint32_t* v_in,
+                      uint32_t* v_out, uint32_t n, int end_bit);      // pm_gpu_build.hip
+
 template <bool COUNT, int KIND>
 __global__ __launch_bounds__(TB) PM_TRAV_ATTR(true, KIND) void shadow_kernel(SceneArrays sc, PathArrays pa, const uint32_t* __restrict__ count,
                                                     uint32_t* __restrict__ work, uint32_t refill, uint4* __restrict__ defer_list, uint32_t defer_cap,
@@ -1045,6 +1075,8 @@ struct RenderState {
     PmRenderStats stats{};
     std::vector<uint64_t> q_closest, q_shadow;      // queue entries per bounce of the last render (all passes)
     std::vector<hipEvent_t> ev_pool;      // per-launch timing: one event before every kernel of a pass + one after
+    // PBRT_MI355_REORDER: keys / values in and out of the radix sort, its scratch
+    uint32_t* d_sort[4] = {nullptr, nullptr, nullptr, nullptr}; void* d_sort_tmp = nullptr; size_t sort_cap = 0, sort_tmp_bytes = 0;
 };
 
 void pm_render_state_destroy(pm_ctx* c) {
@@ -1054,6 +1086,8 @@ void pm_render_state_destroy(pm_ctx* c) {
     for (hipEvent_t e : r->ev_pool) (void)hipEventDestroy(e);
     void* ptrs[] = {r->d_pool, r->d_mats, r->d_lights, r->d_inf, r->d_prim_ref, r->d_patches, r->d_spheres, r->d_m9, r->d_film};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (uint32_t* p : r->d_sort) if (p) (void)hipFree(p);
+    if (r->d_sort_tmp) (void)hipFree(r->d_sort_tmp);
     delete r;
     c->render = nullptr;
 }
@@ -1429,6 +1463,23 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     if ((rcode = ensure_defer(c, max_paths))) return rcode;
     const bool has_spheres = !c->scene.spheres.empty();
     const int kind = pm_walk_kind(c);      // tree-walk kernel variant
+    // PBRT_MI355_REORDER=<bits per axis, 1..9> (experiment, off by default - measured in profiles/r03/ab_reorder.log): before the
+    // closest-hit launch of every bounce after the first, sort the queue by (Morton code of the ray origin, direction octant) and
+    // walk it in that order.  PBRT_MI355_REORDER_OCT_HIGH=1 puts the octant above the Morton code.  Costs one host read of the
+    // queue length per bounce.  The film does not change (hits do not depend on the order rays are walked in).
+    int reorder_bits = 0, reorder_oct_high = 0;
+    if (const char* e = std::getenv("PBRT_MI355_REORDER")) { int v = std::atoi(e); if (v >= 1 && v <= 9) reorder_bits = v; }
+    if (const char* e = std::getenv("PBRT_MI355_REORDER_OCT_HIGH")) reorder_oct_high = std::atoi(e) == 1;
+    if (c->flat.tris != nullptr || has_spheres) reorder_bits = 0;
+    if (reorder_bits && r->sort_cap < max_paths) {
+        for (uint32_t*& q : r->d_sort) { if (q) (void)hipFree(q); q = nullptr; HIPCHK(c, hipMalloc((void**)&q, max_paths * sizeof(uint32_t))); }
+        if (r->d_sort_tmp) (void)hipFree(r->d_sort_tmp);
+        r->d_sort_tmp = nullptr; r->sort_tmp_bytes = 0;
+        if (pm_sort_pairs_u32(c->stream, nullptr, &r->sort_tmp_bytes, r->d_sort[0], r->d_sort[1], r->d_sort[2], r->d_sort[3], (uint32_t)max_paths, 30))
+            return fail(c, PM_ERR_HIP, "pm_render: radix sort size query failed");
+        HIPCHK(c, hipMalloc(&r->d_sort_tmp, std::max<size_t>(r->sort_tmp_bytes, 16)));
+        r->sort_cap = max_paths;
+    }
 
     RenderConst rc{};
     std::memcpy(rc.cfr, r->cam.camera_from_raster, 64); std::memcpy(rc.rfc, r->cam.render_from_camera, 48);
@@ -1499,6 +1550,23 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
                 wslot = 0;
             }
             mark(1);
+            const uint32_t* perm = nullptr;
+            if (reorder_bits && b >= 1) {
+                uint32_t n_q = 0;
+                HIPCHK(c, hipMemcpyAsync(&n_q, cnt_in, sizeof(n_q), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (n_q >= 4096u) {
+                    const pm::Box& bx = c->accel.bounds;
+                    const float q = (float)(1u << reorder_bits);
+                    auto sc1 = [&](int k) { const float e = bx.hi[k] - bx.lo[k]; return e > 0.0f ? q / e : 0.0f; };
+                    hipLaunchKernelGGL(reorder_key_kernel, dim3((n_q + RB - 1) / RB), dim3(RB), 0, c->stream, pa, gen, n_q, mk3(bx.lo[0], bx.lo[1], bx.lo[2]),
+                                       mk3(sc1(0), sc1(1), sc1(2)), reorder_bits, reorder_oct_high, r->d_sort[0], r->d_sort[2]);
+                    size_t tb = r->sort_tmp_bytes;
+                    if (pm_sort_pairs_u32(c->stream, r->d_sort_tmp, &tb, r->d_sort[0], r->d_sort[1], r->d_sort[2], r->d_sort[3], n_q, 3 * reorder_bits + 3))
+                        return fail(c, PM_ERR_HIP, "pm_render: radix sort failed");
+                    perm = r->d_sort[3];
+                }
+            }
             if (flat) {
                 auto kernel = c->counting ? (fpatch ? closest_flat_kernel<true, true> : closest_flat_kernel<true, false>)
                                           : (fpatch ? closest_flat_kernel<false, true> : closest_flat_kernel<false, false>);
@@ -1506,7 +1574,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
             } else {
                 auto kernel = c->counting ? (kind == PM_WALK_MIXED ? closest_kernel<true, PM_WALK_MIXED> : kind == PM_WALK_PATCH ? closest_kernel<true, PM_WALK_PATCH> : closest_kernel<true, PM_WALK_TRI>)
                                           : (kind == PM_WALK_MIXED ? closest_kernel<false, PM_WALK_MIXED> : kind == PM_WALK_PATCH ? closest_kernel<false, PM_WALK_PATCH> : closest_kernel<false, PM_WALK_TRI>);
-                hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, gen, cnt_in, c->d_work + wslot, c->refill, c->d_defer, (uint32_t)c->defer_cap, c->d_counters);
+                hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, gen, cnt_in, c->d_work + wslot, c->refill, c->d_defer, (uint32_t)c->defer_cap, c->d_counters, perm);
             }
             if (has_spheres || flat) {     // second pass: dense exact tests of what was deferred (timed with the closest-hit class)
                 if (c->counting) hipLaunchKernelGGL(closest_fix_kernel<true>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, gen, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
@@ -1518,7 +1586,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
                 HIPCHK(c, hipMemcpyAsync(verify_hits, pa.hit, (size_t)npaths * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
                 if (wslot + 2 > PM_WORK_SLOTS) { HIPCHK(c, hipMemsetAsync(c->d_work, 0, 3 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream)); wslot = 0; }
                 auto kernel = kind == PM_WALK_MIXED ? closest_kernel<true, PM_WALK_MIXED> : kind == PM_WALK_PATCH ? closest_kernel<true, PM_WALK_PATCH> : closest_kernel<true, PM_WALK_TRI>;
-                hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, gen, cnt_in, c->d_work + wslot, c->refill, c->d_defer, (uint32_t)c->defer_cap, c->d_counters);
+                hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, gen, cnt_in, c->d_work + wslot, c->refill, c->d_defer, (uint32_t)c->defer_cap, c->d_counters, (const uint32_t*)nullptr);
                 ++wslot;
                 hipLaunchKernelGGL(verify_hits_kernel, gr, dim3(RB), 0, c->stream, pa, gen, cnt_in, verify_hits, (uint32_t)b, verify_bad, verify_recs, 64u);
             }

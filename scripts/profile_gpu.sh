@@ -14,12 +14,15 @@ step stats-trace
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_trace -o trace --output-format csv -- python3 bench.py --workload trace --steps 5 --warmup 1 --no-cpu-baseline > $OUT/stats_trace.log 2>&1 || exit 1
 step stats-c4
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_c4 -o c4 --output-format csv -- python3 bench.py --workload c4 --spp 8 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/stats_c4.log 2>&1 || exit 1
+step stats-patch
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_patch -o patch --output-format csv -- python3 bench.py --workload patch --steps 5 --warmup 1 --no-cpu-baseline > $OUT/stats_patch.log 2>&1 || exit 1
 step stats-c5
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_c5 -o c5 --output-format csv -- python3 bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/stats_c5.log 2>&1 || exit 1
-for W in ${PROFILE_WORKLOADS:-path trace c4 c5}; do
+for W in ${PROFILE_WORKLOADS:-path trace patch c4 c5}; do
   case $W in
     path) ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-secondary";;
     trace) ARGS="--workload trace --steps 1 --warmup 0 --no-cpu-baseline --no-secondary";;   # primary rays only: one kernel, one ray set
+    patch) ARGS="--workload patch --steps 1 --warmup 0 --no-cpu-baseline --no-secondary";;
     c4) ARGS="--workload c4 --spp 8 --steps 1 --warmup 0 --no-cpu-baseline";;
     c5) ARGS="--workload c5 --steps 1 --warmup 0 --no-cpu-baseline";;
   esac
@@ -32,5 +35,8 @@ for W in ${PROFILE_WORKLOADS:-path trace c4 c5}; do
   step pmc-lanes-$W
   timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_lanes_$W -o l --output-format csv -- python3 bench.py $ARGS > $OUT/pmc_lanes_$W.log 2>&1 || exit 1
 done
+# lanes of the C4 closest-hit walk with the queue sorted per bounce (compare pmc_lanes_c4)
+step pmc-lanes-c4-reorder
+PBRT_MI355_REORDER=5 timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_lanes_c4_reorder -o l --output-format csv -- python3 bench.py --workload c4 --spp 8 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_lanes_c4_reorder.log 2>&1 || exit 1
 step done
 ls -R $OUT | head -60 >> $OUT/progress.log
