@@ -955,6 +955,8 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                 }
                 // ---- descend into the interior children that were hit
                 cur = make_uint2(n1.x, (imask << 8) | PM_PERM8(hits & imask));
+                // (prefetching the node the next step visits - two plain loads issued here - was measured in round 3: 2.5 - 3 %
+                // slower on C3 and C4, profiles/r03/ab_prefetch_next_node.log; the walk is issue-bound, not fetch-latency-bound)
             }
         }
         if (DEFERL) {       // one pre-filter trip for the walking lanes, when enough of them have a leaf parked
