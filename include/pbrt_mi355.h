@@ -192,10 +192,13 @@ typedef struct PmMaterial {
 /* lights/{point,directional,infinite}.rs; `spectrum` is the light's DenselySampledSpectrum (471 floats) */
 enum { PM_LIGHT_POINT = 0, PM_LIGHT_DIRECTIONAL = 1, PM_LIGHT_UNIFORM_INFINITE = 2,
        /* EXTENSION (the reference has no area light: lights/base.rs:18-22, although GeometricPrimitive carries an `area_light`
-        * field, primitives/single.rs:13-19): a diffuse emitter on the patch / triangle `prim_id`, radiance scale * spectrum on the
-        * side its surface normal faces (both sides if two_sided).  Sampled through BilinearPatch::sample_with_context's
-        * area-sampling branch (shapes/bilinear_patch.rs:260-352; the spherical-rectangle branch is todo!() upstream); seen by
-        * rays through SurfaceInteraction::emitted_radiance (core/interaction.rs:179-184, simple_path.rs:156-158). */
+        * field, primitives/single.rs:13-19): a diffuse emitter on the patch / triangle / sphere `prim_id`, radiance scale * spectrum on
+        * the side its surface normal faces (both sides if two_sided).  Sampled through BilinearPatch::sample_with_context's
+        * area-sampling branch (shapes/bilinear_patch.rs:260-352; the spherical-rectangle branch is todo!() upstream) or - round 3 -
+        * Sphere::sample_with_context (shapes/sphere.rs:135-213: by area from inside, within the subtended cone from outside,
+        * restated operation for operation INCLUDING upstream's cos_alpha expression, which differs from pbrt-v4's and crowds the
+        * samples onto the point of the sphere nearest to the receiver); seen by rays through
+        * SurfaceInteraction::emitted_radiance (core/interaction.rs:179-184, simple_path.rs:156-158). */
        PM_LIGHT_DIFFUSE_AREA = 3 };
 typedef struct PmLight {
     int32_t type; float scale; float render_from_light[16]; const float* spectrum;
@@ -295,6 +298,10 @@ int pm_debug_uniforms(pm_ctx* ctx, int32_t px, int32_t py, uint32_t seed, uint64
  * evaluates them in f64 and rounds once (csrc/pm_crmath.hpp).  which: 0 atanh (|x| < 1), 1 cosh (|x| <= 2.2), 2 exp, 3 log,
  * 4 / 5 sin / cos of an azimuth in [0, 2 pi], 6 / 7 sin / cos of the concentric-disk angle in [-pi/4, 3 pi/4] */
 int pm_debug_math(pm_ctx* ctx, int32_t which, const float* x, int32_t n, float* out);
+/* Test hook (round 3): Sphere::sample_with_context (shapes/sphere.rs:135-213) of the sphere `prim_id` of the scene the last
+ * pm_render uploaded, evaluated on the device.  Item i: in8 = ctx_p[3], p_origin[3] (ctx.offset_ray_origin_towards(centre), or
+ * ctx_p for a point in a medium), u[2]; out8 = ok (1 / 0), p[3], n[3], pdf.  Host pointers. */
+int pm_debug_sphere_sample(pm_ctx* ctx, uint32_t prim_id, const float* in8, int32_t n, float* out8);
 
 /* test hook (host state only, works on a host-only context): out4 = { medium set ? 1 : 0, g, sigma_a[0], sigma_s[0] } of the
  * medium the next render would use - shows that a rejected pm_set_medium left the previous state in place */

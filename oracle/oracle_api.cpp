@@ -490,6 +490,38 @@ int ora_patch_sample_ctx(const float* p12, const float* ref_p3, const float* u2,
     out7[0] = m.x; out7[1] = m.y; out7[2] = m.z; out7[3] = ss.n.x; out7[4] = ss.n.y; out7[5] = ss.n.z; out7[6] = ss.pdf;
     return 1;
 }
+// Sphere::sample_with_context (ref_integrator.h sphere_sample_ctx): sphere = (radius, z_min, z_max, phi_max_deg, reverse) + the two
+// 4 x 4 matrices; ctx_n3 may be null (a point in a medium: no offset).  The context's position error is zero here.
+int ora_sphere_sample_ctx(const float* sph5, const float* rfo16, const float* ofr16, const float* ctx_p3, const float* ctx_n3,
+                          const float* u2, float* out7) {
+    M4 rfo, ofr;
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { rfo.m[r][c] = rfo16[4 * r + c]; ofr.m[r][c] = ofr16[4 * r + c]; }
+    Sphere sp = make_sphere(sph5[0], sph5[1], sph5[2], sph5[3], rfo, ofr, sph5[4] != 0.0f);
+    V3 cp(ctx_p3[0], ctx_p3[1], ctx_p3[2]);
+    V3 po = cp;
+    if (ctx_n3) {
+        V3fi pi(Interval(cp.x, cp.x), Interval(cp.y, cp.y), Interval(cp.z, cp.z));
+        po = offset_ray_origin(pi, V3(ctx_n3[0], ctx_n3[1], ctx_n3[2]), sphere_center(sp) - cp);
+    }
+    ShapeSample ss;
+    if (!sphere_sample_ctx(sp, cp, po, P2{u2[0], u2[1]}, &ss)) return 0;
+    V3 m = ss.pi.midpoints();
+    out7[0] = m.x; out7[1] = m.y; out7[2] = m.z; out7[3] = ss.n.x; out7[4] = ss.n.y; out7[5] = ss.n.z; out7[6] = ss.pdf;
+    return 1;
+}
+// batch form for the device comparison (tests/test_sphere_light_gpu.py): item i: in8 = ctx_p[3], p_origin[3], u[2]; out8 = ok, p[3], n[3], pdf
+void ora_sphere_sample_ctx_batch(const float* sph5, const float* rfo16, const float* ofr16, const float* in8, int n, float* out8) {
+    M4 rfo, ofr;
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { rfo.m[r][c] = rfo16[4 * r + c]; ofr.m[r][c] = ofr16[4 * r + c]; }
+    Sphere sp = make_sphere(sph5[0], sph5[1], sph5[2], sph5[3], rfo, ofr, sph5[4] != 0.0f);
+    for (int i = 0; i < n; ++i) {
+        const float* q = in8 + 8 * (size_t)i; float* o = out8 + 8 * (size_t)i;
+        ShapeSample ss; ss.n = V3(0.0f, 0.0f, 0.0f); ss.pdf = 0.0f;
+        bool ok = sphere_sample_ctx(sp, V3(q[0], q[1], q[2]), V3(q[3], q[4], q[5]), P2{q[6], q[7]}, &ss);
+        V3 m = ok ? ss.pi.midpoints() : V3(0.0f, 0.0f, 0.0f);
+        o[0] = ok ? 1.0f : 0.0f; o[1] = m.x; o[2] = m.y; o[3] = m.z; o[4] = ss.n.x; o[5] = ss.n.y; o[6] = ss.n.z; o[7] = ss.pdf;
+    }
+}
 int ora_patch_is_rectangle(const float* p12) {
     Patch p; auto P = [&](int k) { return V3(p12[3 * k], p12[3 * k + 1], p12[3 * k + 2]); };
     p.p00 = P(0); p.p10 = P(1); p.p01 = P(2); p.p11 = P(3);

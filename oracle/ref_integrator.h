@@ -280,6 +280,67 @@ static inline bool patch_sample_ctx(const Patch& p, V3 ref_p, P2 u, ShapeSample*
     return true;
 }
 
+// ---- shape sampling of spheres (shapes/sphere.rs:100-213) -------------------------------------------------------------
+// Sphere::sample (:104-133): a uniform point of the FULL sphere (z / phi clipping is ignored there), pdf = 1 / area() where
+// area() = phi_max * radius * (z_max - z_min) (:100-102).  uv is computed upstream but read by nobody here.
+static inline bool sphere_sample(const Sphere& s, P2 u, ShapeSample* out) {
+    V3 p_obj = V3(0.0f, 0.0f, 0.0f) + s.radius * sample_uniform_sphere(u);
+    p_obj = p_obj * (s.radius / distance(p_obj, V3(0.0f, 0.0f, 0.0f)));
+    V3 p_err = gamma_n(5) * vabs(p_obj);
+    V3 n = normalized(xf_normal(s.object_from_render, p_obj));        // render_from_object * Normal3f: transposed inverse
+    if (s.reverse_orientation) n = n * -1.0f;
+    out->pi = xf_point_fi(s.render_from_object, V3fi::with_err(p_obj, p_err));
+    out->n = n;
+    out->pdf = 1.0f / (s.phi_max * s.radius * (s.z_max - s.z_min));
+    return true;
+}
+// Sphere::sample_with_context (:135-213).  The context is a surface point (pi with its error, geometric normal n: the origin
+// used for the inside / outside decision is offset along n, shapes/base.rs:93-99) or - has_n false - a point in a medium,
+// where upstream would unwrap a None normal; such a context takes the point itself (extension, as pbrt-v4 does).
+static inline V3 sphere_center(const Sphere& s) { return xf_point(s.render_from_object, V3(0.0f, 0.0f, 0.0f)); }
+// ctx_p: ctx.pi.midpoints(); p_origin: ctx.offset_ray_origin_towards(p_center), or ctx_p itself for a point in a medium
+static inline bool sphere_sample_ctx(const Sphere& s, V3 ctx_p, V3 p_origin, P2 u, ShapeSample* out) {
+    V3 p_center = sphere_center(s);
+    if (distance_squared(p_origin, p_center) <= s.radius * s.radius) {         // inside: by area, converted to solid angle
+        if (!sphere_sample(s, u, out)) return false;
+        V3 wi = out->pi.midpoints() - ctx_p;
+        if (length_squared(wi) == 0.0f) return false;
+        wi = normalized(wi);
+        out->pdf /= absdot(out->n, -wi) / distance_squared(ctx_p, out->pi.midpoints());
+        if (std::isinf(out->pdf)) return false;
+        return true;
+    }
+    // outside: uniformly within the cone the sphere subtends
+    float sin_theta_max = s.radius / distance(ctx_p, p_center);
+    float sin2_theta_max = sin_theta_max * sin_theta_max;
+    float cos_theta_max = safe_sqrt(1.0f - sin2_theta_max);
+    float one_minus_cos_theta_max = 1.0f - cos_theta_max;
+    float cos_theta = (cos_theta_max - 1.0f) * u.x + 1.0f;
+    float sin2_theta = 1.0f - cos_theta * cos_theta;
+    if (sin2_theta_max < 0.00068523f) {               // < sin^2(1.5 deg): Taylor expansion
+        sin2_theta = sin2_theta_max * u.x;
+        cos_theta = std::sqrt(1.0f - sin2_theta);
+        one_minus_cos_theta_max = sin2_theta_max / 2.0f;
+    }
+    // (as written upstream: sin2_theta / sin_theta_max * sin2_theta_max under the root, :180-181)
+    float cos_alpha = sin2_theta / sin_theta_max + cos_theta * safe_sqrt(1.0f - sin2_theta / sin_theta_max * sin2_theta_max);
+    float sin_alpha = safe_sqrt(1.0f - cos_alpha * cos_alpha);
+    float phi = u.y * 2.0f * PI_F;
+    float st = clampf(sin_alpha, -1.0f, 1.0f), ct = clampf(cos_alpha, -1.0f, 1.0f);      // spherical_direction, vec_math.rs:40-46
+    V3 w(st * t_cos(phi), st * t_sin(phi), ct);
+    V3 fz = normalized(p_center - ctx_p), fx, fy;                      // Frame::from_z (frame.rs:62-65)
+    coordinate_system(fz, &fx, &fy);
+    V3 mw = -w;
+    V3 n = mw.x * fx + mw.y * fy + mw.z * fz;                          // from_local (frame.rs:68-71)
+    V3 pt = p_center + s.radius * n;
+    if (s.reverse_orientation) n = n * -1.0f;
+    V3 p_err = gamma_n(5) * vabs(pt);
+    out->pi = V3fi::with_err(pt, p_err);
+    out->n = n;
+    out->pdf = 1.0f / (2.0f * PI_F * one_minus_cos_theta_max);
+    return true;
+}
+
 struct FilterSamplerO {                                  // imaging/filter.rs:177-225 + routines.rs:436-503
     int kind; float rx, ry; int nx = 0, ny = 0; std::vector<float> vals; std::vector<PC1D> cond; PC1D marg;
     void init(const OFilm& f) {
@@ -559,6 +620,7 @@ struct Renderer {
     std::vector<int> infinite_lights;
     std::vector<int> prim_area_light;         // by prim id: index of the DiffuseAreaLight on that primitive, or -1
     std::vector<int> prim_patch;              // by prim id: index into scene->patches (-1 for spheres)
+    std::vector<int> prim_sphere;             // by prim id: index into scene->spheres (-1 for patches / triangles)
     bool have_medium = false; OMedium medium{};
     OCamera cam; OFilm film; FilterSamplerO fsampler;
     V3 scene_center; float scene_radius;
@@ -570,7 +632,9 @@ struct Renderer {
         infinite_lights.clear();
         for (size_t i = 0; i < lights.size(); ++i) if (lights[i].type == LIGHT_UNIFORM_INFINITE) infinite_lights.push_back((int)i);
         prim_area_light.assign(prim_material.size(), -1); prim_patch.assign(prim_material.size(), -1);
+        prim_sphere.assign(prim_material.size(), -1);
         for (const Prim& p : scene->prims) if (p.type != PRIM_SPHERE && p.id < prim_patch.size()) prim_patch[p.id] = (int)p.index;
+        for (const Prim& p : scene->prims) if (p.type == PRIM_SPHERE && p.id < prim_sphere.size()) prim_sphere[p.id] = (int)p.index;
         for (size_t i = 0; i < lights.size(); ++i)          // GeometricPrimitive.area_light (primitives/single.rs:13-19)
             if (lights[i].type == LIGHT_DIFFUSE_AREA && lights[i].prim_id < prim_area_light.size()) prim_area_light[lights[i].prim_id] = (int)i;
         int w = film.bounds[2] - film.bounds[0], h = film.bounds[3] - film.bounds[1];
@@ -619,7 +683,9 @@ struct Renderer {
         return tr;
     }
     // Light::sample_li for every light type.  ref_p: the receiving point; returns false when the sample carries nothing.
-    bool sample_light(const OLight& lt, V3 ref_p, P2 u2, const Wavelengths& w, Spec4* Ls, V3* wi, float* pdf, V3* p_light) const {
+    // ctx: the receiving SURFACE point (sphere emitters offset their inside / outside test along its normal); null in a medium
+    bool sample_light(const OLight& lt, V3 ref_p, P2 u2, const Wavelengths& w, Spec4* Ls, V3* wi, float* pdf, V3* p_light,
+                      const SurfInt* ctx = nullptr) const {
         if (lt.type == LIGHT_UNIFORM_INFINITE) {
             *wi = sample_uniform_sphere(u2); *pdf = INV_4_PI; *Ls = light_L(lt, w);
             *p_light = ref_p + *wi * (2.0f * scene_radius);
@@ -635,9 +701,15 @@ struct Renderer {
             *p_light = p;
         } else {      // DiffuseAreaLight::sample_li over BilinearPatch::sample_with_context
             int pi = lt.prim_id < prim_patch.size() ? prim_patch[lt.prim_id] : -1;
-            if (pi < 0) return false;
+            int si = lt.prim_id < prim_sphere.size() ? prim_sphere[lt.prim_id] : -1;
+            if (pi < 0 && si < 0) return false;
             ShapeSample ss;
-            if (!patch_sample_ctx(scene->patches[pi], ref_p, u2, &ss)) return false;
+            if (si >= 0) {          // ... or over Sphere::sample_with_context
+                const Sphere& sph = scene->spheres[si];
+                V3 ctx_p = ctx ? ctx->pi.midpoints() : ref_p;
+                V3 p_origin = ctx ? offset_ray_origin(ctx->pi, ctx->n, sphere_center(sph) - ctx_p) : ctx_p;
+                if (!sphere_sample_ctx(sph, ctx_p, p_origin, u2, &ss)) return false;
+            } else if (!patch_sample_ctx(scene->patches[pi], ref_p, u2, &ss)) return false;
             V3 pl = ss.pi.midpoints();
             if (ss.pdf == 0.0f || length_squared(pl - ref_p) == 0.0f) return false;
             *wi = normalized(pl - ref_p);
@@ -810,7 +882,7 @@ struct Renderer {
                     P2 u2; u2.x = rng->uniform_float(); u2.y = rng->uniform_float();
                     Spec4 Ls; V3 wi, p_light; float pdf;
                     V3 pm = si.pi.midpoints();
-                    if (sample_light(lights[idx], pm, u2, *w, &Ls, &wi, &pdf, &p_light) && !spec_all_zero(Ls) && pdf > 0.0f) {
+                    if (sample_light(lights[idx], pm, u2, *w, &Ls, &wi, &pdf, &p_light, &si) && !spec_all_zero(Ls) && pdf > 0.0f) {
                         Spec4 f = bsdf.eval(wo, wi);
                         float ad = absdot(wi, si.ns);
                         for (int i = 0; i < NSP; ++i) f.v[i] *= ad;

@@ -136,6 +136,7 @@ SYMBOLS = {
     "pm_debug_sample": (C.c_int, [_P, C.POINTER(PmRenderParams), C.c_int32, C.c_int32, C.c_int32, _P, C.c_uint32]),
     "pm_debug_uniforms": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int32, _P]),
     "pm_debug_math": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P]),
+    "pm_debug_sphere_sample": (C.c_int, [_P, C.c_uint32, _P, C.c_int32, _P]),
     "pm_debug_medium_state": (C.c_int, [_P, C.POINTER(C.c_float)]),
     # include/pbrt_mi355_host.h
     "pmh_mat4_inverse": (C.c_int, [_P, _P]),

@@ -171,6 +171,14 @@ class GpuAggregate:
         self._check(self._lib.pm_debug_math(self._h, which, x.ctypes.data, len(x), out.ctypes.data))
         return out
 
+    def debug_sphere_sample(self, prim_id, in8):
+        """Sphere::sample_with_context of sphere `prim_id` on the device; rows of in8: ctx_p[3], p_origin[3], u[2]; rows of the result:
+        ok, p[3], n[3], pdf (include/pbrt_mi355.h pm_debug_sphere_sample; after a pm_render of the scene) — test hook"""
+        in8 = np.ascontiguousarray(in8, np.float32).reshape(-1, 8)
+        out = np.zeros((len(in8), 8), np.float32)
+        self._check(self._lib.pm_debug_sphere_sample(self._h, prim_id, in8.ctypes.data, len(in8), out.ctypes.data))
+        return out
+
     def last_kernel_ms(self):
         ms = C.c_float()
         self._check(self._lib.pm_last_kernel_ms(self._h, C.byref(ms)))

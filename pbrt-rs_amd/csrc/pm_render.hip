@@ -417,9 +417,12 @@ __device__ __forceinline__ Bsdf make_bsdf(const SceneArrays& sc, const PathArray
 
 // Light::sample_li of every light type for the receiving point pm (lights/{point,directional,infinite}.rs; DiffuseAreaLight
 // over BilinearPatch::sample_with_context is an extension, EXT kernels only).  false: the sample carries nothing.
-template <bool EXT>
+// SPH (round 3): the scene has area lights on SPHERES (Sphere::sample_with_context); ctx is then the receiving surface point
+// (null for a vertex in the medium).
+template <bool EXT, bool SPH = false>
 __device__ __forceinline__ bool sample_light(const RenderConst& rc, const SceneArrays& sc, const DLight& lt, f3 pm, f2 u2,
-                                             const float* lam, Spec4* Ls, f3* wi, float* lpdf, f3* p_light) {
+                                             const float* lam, Spec4* Ls, f3* wi, float* lpdf, f3* p_light,
+                                             const SurfInt* ctx = nullptr) {
     *Ls = light_L(sc, lt, lam);
     if (lt.type == PM_LIGHT_UNIFORM_INFINITE) {
         *wi = sample_uniform_sphere(u2); *lpdf = PM_INV_4PI;
@@ -441,7 +444,11 @@ __device__ __forceinline__ bool sample_light(const RenderConst& rc, const SceneA
     } else {
         ShapeSample ss;
         const uint32_t ref = shade_ref(sc, lt.prim_id);
-        if (!patch_sample_ctx(sc.patches[ref & 0x3FFFFFFFu], sc.pool, lt.m, lt.m[4] != 0.0f, pm, u2, &ss)) return false;
+        if (SPH && (ref >> 30) == PM_PRIM_SPHERE) {
+            const DShadeSphere& sph = sc.spheres[ref & 0x3FFFFFFFu];
+            const f3 po = ctx ? offset_ray_origin(*ctx, sphere_center(sph) - pm) : pm;
+            if (!sphere_sample_ctx(sph, pm, po, u2, &ss)) return false;
+        } else if (!patch_sample_ctx(sc.patches[ref & 0x3FFFFFFFu], sc.pool, lt.m, lt.m[4] != 0.0f, pm, u2, &ss)) return false;
         const f3 dv = ss.p - pm;
         if (ss.pdf == 0.0f || dot3(dv, dv) == 0.0f) return false;
         *wi = norm3(dv);
@@ -495,7 +502,8 @@ __device__ __forceinline__ bool block_regroup(int* kind, uint32_t (&w)[PM_XCH_WO
 // EXT: the integrator is PM_INTEGRATOR_VOL_PATH with a medium set, or the scene holds textured materials.  That code (the medium
 // event as a third outcome beside "surface" and "escaped", the regrouping of a block's vertices, texture lookups) is compiled only
 // into the EXT variant: it costs registers, and the plain variant is the hot kernel of the C2 / C4 frames.
-// AREA (plain variant only; round 3): the scene holds diffuse area lights but neither a medium nor textures - SURVEY 8(d)'s C2, a
+// AREA with EXT (round 3): the scene has area lights on SPHERES; only that instantiation carries Sphere::sample_with_context.
+// AREA (plain variant; round 3): the scene holds diffuse area lights but neither a medium nor textures - SURVEY 8(d)'s C2, a
 // Cornell box under a ceiling quad emitter.  The plain straight-line body plus emission on a hit and the shape-sampling branch of
 // sample_light; round 2 sent such scenes through the EXT kernel.
 template <bool EXT, bool AREA = false>
@@ -771,7 +779,7 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                 uint32_t mat_id, rec_flags = 0u;
                 if ((ref >> 30) == PM_PRIM_SPHERE) {
                     const DShadeSphere& ss = sc.spheres[ref & 0x3FFFFFFFu];
-                    mat_id = ss.mat;
+                    mat_id = ss.mat; rec_flags = ss.flags;
                     si = sphere_interaction(ss, mk3(ro4.x, ro4.y, ro4.z), rd, hv.y);
                 } else {
                     const DShadePatch& sp = sc.patches[ref & 0x3FFFFFFFu];
@@ -809,7 +817,7 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
                         const float prob = 1.0f / (float)rc.n_lights;
                         f2 u2; u2.x = rng_uniform(&rng); u2.y = rng_uniform(&rng);
                         Spec4 Ls; f3 wi, p_light; float lpdf;
-                        if (sample_light<EXT>(rc, sc, sc.lights[idx], vp, u2, lam, &Ls, &wi, &lpdf, &p_light) && !spec_zero(Ls) && lpdf > 0.0f) {
+                        if (sample_light<EXT, AREA>(rc, sc, sc.lights[idx], vp, u2, lam, &Ls, &wi, &lpdf, &p_light, vtx_medium ? nullptr : &si) && !spec_zero(Ls) && lpdf > 0.0f) {
                             Spec4 f;
                             if (EXT && vtx_medium) f = spec_c(henyey_greenstein(dot3(wo, wi), rc.med_g));
                             else {
@@ -1057,7 +1065,7 @@ struct RenderState {
     std::vector<uint32_t> prim_mat;
     std::vector<PmLight> lights; std::vector<std::vector<float>> light_tables;
     bool have_medium = false; PmMedium medium{}; std::vector<float> med_sigma_a, med_sigma_s;
-    int med_off_a = 0, med_off_s = 0; bool have_area_lights = false; bool direct_records = false;
+    int med_off_a = 0, med_off_s = 0; bool have_area_lights = false; bool have_sphere_lights = false; bool direct_records = false;
     PmCamera cam{}; bool have_cam = false;
     PmFilm film{}; bool have_film = false;
     std::vector<float> sensor, filter_vals;
@@ -1305,8 +1313,9 @@ static int upload_scene(pm_ctx* c, RenderState* r) {
         prim_light[dl[i].prim_id] = (int)i;
         r->have_area_lights = true;
     }
+    r->have_sphere_lights = false;
     for (const auto& sph : c->scene.spheres)
-        if (!prim_light.empty() && prim_light[sph.prim_id] >= 0) return fail(c, PM_ERR_UNSUPPORTED, "pm_render: area lights on spheres are not supported (patches and triangles only)");
+        if (!prim_light.empty() && prim_light[sph.prim_id] >= 0) r->have_sphere_lights = true;
     if (r->have_medium) { r->med_off_a = add_table(r->med_sigma_a); r->med_off_s = add_table(r->med_sigma_s); }
     r->n_inf = (int)inf.size();
     r->sensor_off = add_table(r->sensor);
@@ -1366,18 +1375,19 @@ static int upload_scene(pm_ctx* c, RenderState* r) {
         DShadeSphere d{};
         std::memcpy(d.rfo, s.render_from_object, 48); std::memcpy(d.ofr, s.object_from_render, 48);
         d.radius = s.radius; d.z_min = s.z_min; d.z_max = s.z_max; d.phi_max = s.phi_max; d.th_min = s.theta_z_min; d.th_max = s.theta_z_max;
-        d.flags = s.reverse_orientation ? 1u : 0u;
+        d.flags = (s.reverse_orientation ? 1u : 0u) | light_bits(s.prim_id);
         d.mat = r->prim_mat[s.prim_id];
         ref[s.prim_id] = ((uint32_t)PM_PRIM_SPHERE << 30) | (uint32_t)ss.size(); ss.push_back(d);
     }
     // BilinearPatch::sample's per-patch constants of every area light (pm_shade.hpp patch_area_constants), in DLight.m
     for (size_t i = 0; i < dl.size(); ++i) {
         if (dl[i].type != PM_LIGHT_DIFFUSE_AREA) continue;
-        // (the emitter's record: a triangle's holds v0 v1 v2 v2, the degenerate patch it is; spheres were rejected above)
+        std::memset(dl[i].m, 0, sizeof(dl[i].m));
+        if (!direct && (ref[dl[i].prim_id] >> 30) == PM_PRIM_SPHERE) continue;        // a sphere emitter: nothing to precompute
+        // (the emitter's record: a triangle's holds v0 v1 v2 v2, the degenerate patch it is)
         const float* q = direct ? sp[dl[i].prim_id].p : sp[ref[dl[i].prim_id] & 0x3FFFFFFFu].p;
         float w4[4]; bool rect = false;
         patch_area_constants(mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), mk3(q[6], q[7], q[8]), mk3(q[9], q[10], q[11]), w4, &rect);
-        std::memset(dl[i].m, 0, sizeof(dl[i].m));
         for (int k = 0; k < 4; ++k) dl[i].m[k] = w4[k];
         dl[i].m[4] = rect ? 1.0f : 0.0f;
     }
@@ -1492,7 +1502,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     rc.terminal_emission = (r->n_inf > 0 || r->have_area_lights) ? 1 : 0;
     rc.med_sigma_a = r->med_off_a; rc.med_sigma_s = r->med_off_s; rc.med_g = r->medium.g;
     std::memcpy(rc.med_bounds, r->medium.bounds, sizeof(rc.med_bounds));
-    const bool shade_ext = rc.medium_on || r->have_textures;
+    const bool shade_ext = rc.medium_on || r->have_textures || r->have_sphere_lights;      // (sphere emitters: EXT kernels only)
     const bool shade_area = r->have_area_lights && !shade_ext;
     bool force_ext = false;         // A/B and tests: PBRT_MI355_SHADE_EXT=1 routes area-light scenes through the EXT kernel as round 2 did
     if (const char* e = std::getenv("PBRT_MI355_SHADE_EXT")) force_ext = std::atoi(e) == 1 && r->have_area_lights;
@@ -1592,6 +1602,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
             }
             mark(2);
             if (random_walk) hipLaunchKernelGGL(shade_rw_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out);
+            else if (r->have_sphere_lights) hipLaunchKernelGGL((shade_kernel<true, true>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out, cnt_sh);
             else if (shade_ext || force_ext) hipLaunchKernelGGL((shade_kernel<true, false>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out, cnt_sh);
             else if (shade_area) hipLaunchKernelGGL((shade_kernel<false, true>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out, cnt_sh);
             else hipLaunchKernelGGL((shade_kernel<false, false>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out, cnt_sh);
@@ -1745,6 +1756,44 @@ extern "C" int pm_debug_math(pm_ctx* c, int32_t which, const float* x, int32_t n
     (void)hipFree(dx);
     if (dout) (void)hipFree(dout);
     if (e != hipSuccess) return fail(c, PM_ERR_HIP, std::string("pm_debug_math: ") + hipGetErrorString(e));
+    return PM_OK;
+}
+// test hook: Sphere::sample_with_context of the sphere `prim_id` of the scene the last pm_render uploaded, item i: in8 = ctx_p[3],
+// p_origin[3], u[2]; out8 = ok, p[3], n[3], pdf
+__global__ void debug_sphere_sample_kernel(SceneArrays sc, uint32_t prim_id, const float* __restrict__ in8, int n, float* __restrict__ out8) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t ref = shade_ref(sc, prim_id);
+    const float* q = in8 + 8 * (size_t)i;
+    f2 u; u.x = q[6]; u.y = q[7];
+    ShapeSample ss; ss.p = mk3(0.f, 0.f, 0.f); ss.n = ss.p; ss.pdf = 0.f;
+    const bool ok = sphere_sample_ctx(sc.spheres[ref & 0x3FFFFFFFu], mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), u, &ss);
+    float* o = out8 + 8 * (size_t)i;
+    o[0] = ok ? 1.0f : 0.0f; o[1] = ss.p.x; o[2] = ss.p.y; o[3] = ss.p.z; o[4] = ss.n.x; o[5] = ss.n.y; o[6] = ss.n.z; o[7] = ss.pdf;
+}
+extern "C" int pm_debug_sphere_sample(pm_ctx* c, uint32_t prim_id, const float* in8, int32_t n, float* out8) {
+    if (!c || !in8 || !out8 || n < 0) return fail(c, PM_ERR_INVALID, "pm_debug_sphere_sample: bad argument");
+    if (c->device < 0 || !c->render) return fail(c, PM_ERR_INVALID, "pm_debug_sphere_sample: nothing rendered on this context");
+    RenderState* r = c->render;
+    if (r->scene_dirty || r->geom_gen != c->geom_gen || r->direct_records) return fail(c, PM_ERR_INVALID, "pm_debug_sphere_sample: render the scene (with spheres) first");
+    bool is_sphere = false;
+    for (const auto& sph : c->scene.spheres) if (sph.prim_id == prim_id) is_sphere = true;
+    if (!is_sphere) return fail(c, PM_ERR_INVALID, "pm_debug_sphere_sample: prim_id is not a sphere");
+    if (n == 0) return PM_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    float *din = nullptr, *dout = nullptr;
+    HIPCHK(c, hipMalloc((void**)&din, (size_t)n * 8 * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&dout, (size_t)n * 8 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(din, in8, (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        SceneArrays sa{c->d_nodes, c->d_prims, r->d_prim_ref, r->d_patches, r->d_spheres, r->d_mats, r->d_lights, r->d_inf, r->d_pool, 0};
+        hipLaunchKernelGGL(debug_sphere_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, sa, prim_id, din, (int)n, dout);
+        e = hipMemcpyAsync(out8, dout, (size_t)n * 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(din);
+    if (dout) (void)hipFree(dout);
+    if (e != hipSuccess) return fail(c, PM_ERR_HIP, std::string("pm_debug_sphere_sample: ") + hipGetErrorString(e));
     return PM_OK;
 }
 extern "C" int pm_get_queue_counts(pm_ctx* c, uint64_t* closest, uint64_t* shadow, uint32_t cap, uint32_t* n_bounces) {

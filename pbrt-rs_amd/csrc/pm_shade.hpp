@@ -421,6 +421,27 @@ PMD bool swaps_handedness12(const float* m) {
     const float det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
     return det < 0.0f;
 }
+// Transform * Point3fi for p = ph +- perr (approximate-p branch, core/transform.rs:371-404), affine 3 x 4 matrix m
+PMD void xf_point_fi12(const float* m, f3 ph, f3 perr, Iv* px, Iv* py, Iv* pz) {
+    const Iv ix = iv_err(ph.x, perr.x), iy = iv_err(ph.y, perr.y), iz = iv_err(ph.z, perr.z);
+    const float x = iv_mid(ix), y = iv_mid(iy), z = iv_mid(iz);
+    const float ex = (ix.hi - ix.lo) / 2.0f, ey = (iy.hi - iy.lo) / 2.0f, ez = (iz.hi - iz.lo) / 2.0f;
+    const float g3 = gamma_n(3);
+    const float xp = (m[0] * x + m[1] * y) + (m[2] * z + m[3]);
+    const float yp = (m[4] * x + m[5] * y) + (m[6] * z + m[7]);
+    const float zp = (m[8] * x + m[9] * y) + (m[10] * z + m[11]);
+    float e0, e1, e2;
+    if (ex == 0.0f && ey == 0.0f && ez == 0.0f && (ix.hi - ix.lo) == 0.0f && (iy.hi - iy.lo) == 0.0f && (iz.hi - iz.lo) == 0.0f) {
+        e0 = g3 * (fabsf(m[0] * x) + fabsf(m[1] * y) + fabsf(m[2] * z) + fabsf(m[3]));
+        e1 = g3 * (fabsf(m[4] * x) + fabsf(m[5] * y) + fabsf(m[6] * z) + fabsf(m[7]));
+        e2 = g3 * (fabsf(m[8] * x) + fabsf(m[9] * y) + fabsf(m[10] * z) + fabsf(m[11]));
+    } else {
+        e0 = (g3 + 1.0f) * (fabsf(m[0]) * ex + fabsf(m[1]) * ey + fabsf(m[2]) * ez) + g3 * (fabsf(m[0] * x) + fabsf(m[1] * y) + fabsf(m[2] * z) + fabsf(m[3]));
+        e1 = (g3 + 1.0f) * (fabsf(m[4]) * ex + fabsf(m[5]) * ey + fabsf(m[6]) * ez) + g3 * (fabsf(m[4] * x) + fabsf(m[5] * y) + fabsf(m[6] * z) + fabsf(m[7]));
+        e2 = (g3 + 1.0f) * (fabsf(m[8]) * ex + fabsf(m[9]) * ey + fabsf(m[10]) * ez) + g3 * (fabsf(m[8] * x) + fabsf(m[9] * y) + fabsf(m[10] * z) + fabsf(m[11]));
+    }
+    *px = iv_err(xp, e0); *py = iv_err(yp, e1); *pz = iv_err(zp, e2);
+}
 // recomputes the reference's QuadricIntersection.p_obj from the ray and t_hit (sphere.rs:320-333), then
 // interaction_from_intersection (sphere.rs:371-442) and SurfaceInteraction::transform
 PMD SurfInt sphere_interaction(const DShadeSphere& s, f3 ro, f3 rd, float t_hit) {
@@ -439,27 +460,9 @@ PMD SurfInt sphere_interaction(const DShadeSphere& s, f3 ro, f3 rd, float t_hit)
     const bool flip = ((s.flags & 1u) != 0u) != swaps_handedness12(s.rfo);
     f3 n = norm3(cross3(dpdu, dpdv));
     if (flip) n = n * -1.0f;
-    // Transform * Point3fi (approximate-p branch, core/transform.rs:371-404)
-    const Iv ix = iv_err(ph.x, perr.x), iy = iv_err(ph.y, perr.y), iz = iv_err(ph.z, perr.z);
-    const float x = iv_mid(ix), y = iv_mid(iy), z = iv_mid(iz);
-    const float ex = (ix.hi - ix.lo) / 2.0f, ey = (iy.hi - iy.lo) / 2.0f, ez = (iz.hi - iz.lo) / 2.0f;
     const float* m = s.rfo;
-    const float g3 = gamma_n(3);
-    const float xp = (m[0] * x + m[1] * y) + (m[2] * z + m[3]);
-    const float yp = (m[4] * x + m[5] * y) + (m[6] * z + m[7]);
-    const float zp = (m[8] * x + m[9] * y) + (m[10] * z + m[11]);
-    float e0, e1, e2;
-    if (ex == 0.0f && ey == 0.0f && ez == 0.0f && (ix.hi - ix.lo) == 0.0f && (iy.hi - iy.lo) == 0.0f && (iz.hi - iz.lo) == 0.0f) {
-        e0 = g3 * (fabsf(m[0] * x) + fabsf(m[1] * y) + fabsf(m[2] * z) + fabsf(m[3]));
-        e1 = g3 * (fabsf(m[4] * x) + fabsf(m[5] * y) + fabsf(m[6] * z) + fabsf(m[7]));
-        e2 = g3 * (fabsf(m[8] * x) + fabsf(m[9] * y) + fabsf(m[10] * z) + fabsf(m[11]));
-    } else {
-        e0 = (g3 + 1.0f) * (fabsf(m[0]) * ex + fabsf(m[1]) * ey + fabsf(m[2]) * ez) + g3 * (fabsf(m[0] * x) + fabsf(m[1] * y) + fabsf(m[2] * z) + fabsf(m[3]));
-        e1 = (g3 + 1.0f) * (fabsf(m[4]) * ex + fabsf(m[5]) * ey + fabsf(m[6]) * ez) + g3 * (fabsf(m[4] * x) + fabsf(m[5] * y) + fabsf(m[6] * z) + fabsf(m[7]));
-        e2 = (g3 + 1.0f) * (fabsf(m[8]) * ex + fabsf(m[9]) * ey + fabsf(m[10]) * ez) + g3 * (fabsf(m[8] * x) + fabsf(m[9] * y) + fabsf(m[10] * z) + fabsf(m[11]));
-    }
     SurfInt si;
-    si.px = iv_err(xp, e0); si.py = iv_err(yp, e1); si.pz = iv_err(zp, e2);
+    xf_point_fi12(m, ph, perr, &si.px, &si.py, &si.pz);
     si.n = xf_normal12(s.ofr, norm3(n));
     si.dpdus = mk3(dpdu.x * m[0] + dpdu.y * m[1] + dpdu.z * m[2], dpdu.x * m[4] + dpdu.y * m[5] + dpdu.z * m[6],
                    dpdu.x * m[8] + dpdu.y * m[9] + dpdu.z * m[10]);
@@ -556,6 +559,69 @@ PMD bool patch_sample_ctx(const DShadePatch& sp, const float* __restrict__ pool,
     pdf /= fabsf(dot3(n, -wi)) / dist2(ref_p, pm);
     if (isinf(pdf)) return false;
     out->p = pm; out->n = n; out->pdf = pdf;
+    return true;
+}
+// Sphere::sample (sphere.rs:104-133): a uniform point of the full sphere, pdf = 1 / area() (:100-102)
+PMD void sphere_sample(const DShadeSphere& s, f2 u, ShapeSample* out) {
+    f3 p_obj = mk3(0.0f, 0.0f, 0.0f) + sample_uniform_sphere(u) * s.radius;
+    p_obj = p_obj * (s.radius / len3(p_obj - mk3(0.0f, 0.0f, 0.0f)));
+    const f3 p_err = abs3(p_obj) * gamma_n(5);
+    f3 n = norm3(xf_normal12(s.ofr, p_obj));
+    if (s.flags & 1u) n = n * -1.0f;
+    Iv px, py, pz;
+    xf_point_fi12(s.rfo, p_obj, p_err, &px, &py, &pz);
+    out->p = mk3(iv_mid(px), iv_mid(py), iv_mid(pz));
+    out->n = n;
+    out->pdf = 1.0f / (s.phi_max * s.radius * (s.z_max - s.z_min));
+}
+// Sphere::sample_with_context (sphere.rs:135-213).  ctx_p: the receiving point; p_origin: the same point offset towards the
+// sphere's centre along the surface normal (ShapeSampleContext::offset_ray_origin_towards), or ctx_p itself in a medium
+PMD f3 sphere_center(const DShadeSphere& s) {
+    const float* m = s.rfo;
+    return mk3(0.0f * m[0] + 0.0f * m[1] + 0.0f * m[2] + m[3], 0.0f * m[4] + 0.0f * m[5] + 0.0f * m[6] + m[7],
+               0.0f * m[8] + 0.0f * m[9] + 0.0f * m[10] + m[11]);
+}
+PMD bool sphere_sample_ctx(const DShadeSphere& s, f3 ctx_p, f3 p_origin, f2 u, ShapeSample* out) {
+    const f3 p_center = sphere_center(s);
+    if (dist2(p_origin, p_center) <= s.radius * s.radius) {        // inside: by area, converted to solid angle
+        sphere_sample(s, u, out);
+        f3 wi = out->p - ctx_p;
+        if (dot3(wi, wi) == 0.0f) return false;
+        wi = norm3(wi);
+        out->pdf /= fabsf(dot3(out->n, -wi)) / dist2(ctx_p, out->p);
+        return !isinf(out->pdf);
+    }
+    const float sin_theta_max = s.radius / len3(ctx_p - p_center);
+    const float sin2_theta_max = sin_theta_max * sin_theta_max;
+    const float cos_theta_max = safe_sqrtf(1.0f - sin2_theta_max);
+    float one_minus_cos_theta_max = 1.0f - cos_theta_max;
+    float cos_theta = (cos_theta_max - 1.0f) * u.x + 1.0f;
+    float sin2_theta = 1.0f - cos_theta * cos_theta;
+    if (sin2_theta_max < 0.00068523f) {
+        sin2_theta = sin2_theta_max * u.x;
+        cos_theta = sqrtf(1.0f - sin2_theta);
+        one_minus_cos_theta_max = sin2_theta_max / 2.0f;
+    }
+    const float cos_alpha = sin2_theta / sin_theta_max + cos_theta * safe_sqrtf(1.0f - sin2_theta / sin_theta_max * sin2_theta_max);
+    const float sin_alpha = safe_sqrtf(1.0f - cos_alpha * cos_alpha);
+    const float phi = u.y * 2.0f * PM_PI;
+    const float st = clampf(sin_alpha, -1.0f, 1.0f), ct = clampf(cos_alpha, -1.0f, 1.0f);
+    float sp, cp; cr_sincos_2pi(phi, &sp, &cp);
+    const f3 w = mk3(st * cp, st * sp, ct);
+    const f3 fz = norm3(p_center - ctx_p);
+    f3 fx, fy;                                         // Frame::from_z via Vec3f::coordinate_system (core/vec.rs:743-757)
+    if (fabsf(fz.x) > fabsf(fz.y)) fx = mk3(-fz.z, 0.0f, fz.x) / sqrtf(fz.x * fz.x + fz.z * fz.z);
+    else fx = mk3(0.0f, fz.z, -fz.y) / sqrtf(fz.y * fz.y + fz.z * fz.z);
+    fy = cross3(fz, fx);
+    const f3 mw = -w;
+    f3 n = mw.x * fx + mw.y * fy + mw.z * fz;
+    const f3 pt = p_center + n * s.radius;
+    if (s.flags & 1u) n = n * -1.0f;
+    const f3 p_err = abs3(pt) * gamma_n(5);
+    const Iv ix = iv_err(pt.x, p_err.x), iy = iv_err(pt.y, p_err.y), iz = iv_err(pt.z, p_err.z);
+    out->p = mk3(iv_mid(ix), iv_mid(iy), iv_mid(iz));
+    out->n = n;
+    out->pdf = 1.0f / (2.0f * PM_PI * one_minus_cos_theta_max);
     return true;
 }
 // the part [t0, t1] of the ray's [0, t_max] inside the medium's bounds

@@ -254,6 +254,7 @@ extern "C" {
     pub fn pm_debug_sample(ctx: *mut pm_ctx, params: *const PmRenderParams, px: i32, py: i32, sample_index: i32, out13: *mut f32, struct_bytes: u32) -> i32;
     pub fn pm_debug_uniforms(ctx: *mut pm_ctx, px: i32, py: i32, seed: u32, sample_index: u64, dimension: u64, n: i32, out: *mut f32) -> i32;
     pub fn pm_debug_math(ctx: *mut pm_ctx, which: i32, x: *const f32, n: i32, out: *mut f32) -> i32;
+    pub fn pm_debug_sphere_sample(ctx: *mut pm_ctx, prim_id: u32, in8: *const f32, n: i32, out8: *mut f32) -> i32;
     pub fn pm_debug_medium_state(ctx: *mut pm_ctx, out4: *mut f32) -> i32;
 }
 

@@ -133,3 +133,55 @@ def test_c2_scene_area_instantiation_bitwise(pm, ora, monkeypatch):
     # the emitter is visible: the brightest pixels of the image lie on it
     img = a.image()
     assert img.max() > 20 * np.median(img)
+
+
+def _sphere_emitter_scene(pm, res, medium=None):
+    """the Cornell box with its glass sphere, lit by SPHERE emitters only (round 3): a small one-sided sphere hanging in the box
+    (receivers are outside it: Sphere::sample_with_context's cone branch), a sphere the size of a pea inside the cone's
+    Taylor-expansion range, and - reverse-oriented, so that it emits inwards - a sphere of radius 6 around the whole scene
+    (every receiver is inside it: the area branch), seen through the open front of the box"""
+    host = pm.host
+    sp = host.Spectra()
+    sd = pm.scenes.cornell_scene(res, glass_sphere=True, area_light=False, medium=medium)
+    rfw = sd.render_from_world
+    sd.lights = []
+    # walls only: the enclosing sphere sends rays up through the floor from BELOW, where the bottom faces of the two boxes coincide
+    # with it - exact-t ties between different primitives, which the reference resolves by tree order (DESIGN.md 3, tie class)
+    mesh = sd.prims[0]
+    sd.prims[0] = pm.TriangleMesh(mesh.positions, mesh.indices[:10])
+    sd.prim_materials = sd.prim_materials[:10] + sd.prim_materials[len(mesh.indices):]
+    for centre, radius, reverse, power, two_sided, table in (((-0.3, 0.55, 0.35), 0.18, False, 30.0, False, sp.d65.copy()),
+                                                            ((0.6, 0.7, -0.5), 0.02, False, 900.0, True, sp.blackbody_table(3200.0)),
+                                                            ((0.0, 0.0, 0.0), 6.0, True, 0.4, False, sp.d65.copy())):
+        t = rfw * host.Transform.translate(centre)
+        sd.prims.append(pm.Sphere(radius, -radius, radius, 360.0, t.m, t.m_inv, reverse))
+        sd.prim_materials.append(0)
+        sd.lights.append(host.area_light(table, power / sp.photometric(table), len(sd.prim_materials) - 1, two_sided=two_sided))
+    return sd
+
+
+def test_sphere_emitters_bitwise(pm, ora):
+    """area lights on spheres (Sphere::sample / sample_with_context, sphere.rs:100-213; round 3): NEE from surface points outside
+    and inside an emitting sphere, emission seen directly, through the glass sphere and by BSDF sampling"""
+    res, spp = (64, 64), 8
+    sd = _sphere_emitter_scene(pm, res)
+    frac, tot = _bit_equal(pm, ora, sd, spp)
+    _report("sphere emitters (cone branch, Taylor branch, enclosing sphere), SimplePath depth 5", frac, tot)
+    assert frac >= 0.9999
+    frac, tot = _bit_equal(pm, ora, sd, 4, max_depth=3, sample_lights=False)
+    _report("sphere emitters, sample_lights off", frac, tot)
+    assert frac >= 0.9999
+    a = pm.WavefrontIntegrator(5, True, True, sd, 4)
+    st = a.render()
+    img = a.image()
+    assert st["shadow_rays"] > 0 and np.isfinite(img).all() and img.max() > 10 * np.median(img) > 0
+
+
+def test_sphere_emitters_in_a_medium_bitwise(pm, ora):
+    """the same lights sampled from vertices INSIDE the medium (no surface normal: the receiving point itself decides inside /
+    outside) by the VolPath integrator"""
+    VOL = pm._capi.PM_INTEGRATOR_VOL_PATH
+    sd = _sphere_emitter_scene(pm, (48, 48), medium=(0.05, 0.6, 0.3))
+    frac, tot = _bit_equal(pm, ora, sd, 8, max_depth=8, integrator=VOL)
+    _report("sphere emitters + homogeneous medium, VolPath depth 8", frac, tot)
+    assert frac >= 0.9999
