@@ -180,7 +180,7 @@ extern "C" int pm_create(int device_id, pm_ctx** out) {
 }
 extern "C" void pm_destroy(pm_ctx* c) {
     if (!c) return;
-    if (c->device < 0) { delete c; return; }
+    if (c->device < 0) { pm_render_state_destroy(c); delete c; return; }      // (host-only: the render state holds host tables only)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     pm_render_state_destroy(c);
