@@ -460,6 +460,11 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup, work
     tag = {"path": "path", "c2pl": "c2pl", "c4": "c4", "c5": "c5"}[workload]
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "kernel": KERNEL_NAMES[dom], "kernel_ms": float(ms_k[dom] / max(1.0, launches[dom])),
+            # the kernel(s) rocprofv3 lists for this class of launches (a class is timed as a whole, events around it)
+            "kernels_in_class": ({"closest_kernel": "closest_flat_kernel<false,*> + closest_fix_kernel<false>", "shadow_kernel":
+                                  "shadow_flat_kernel<false,*> + shadow_fix_kernel<false>"} if info.flat_prims else
+                                 {"closest_kernel": "closest_kernel<false,KIND>", "shadow_kernel": "shadow_kernel<false,KIND>"}
+                                 ).get(KERNEL_NAMES[dom], KERNEL_NAMES[dom]),
             "launches_per_step": float(launches[dom]), "bytes_per_launch": bytes_k[dom] / max(1.0, launches[dom]),
             "demand_GBps": demand_k[dom] / (ms_k[dom] * 1e-3) / 1e9,
             "scene_resident_in_infinity_cache": bool(resident),
@@ -525,7 +530,7 @@ def _roof_short(r):
     """the roofline object of the contract, without the per-kernel tables"""
     if not r:
         return None
-    o = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "kernel_ms",
+    o = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "kernels_in_class", "kernel_ms",
                   "launches_per_step", "bytes_per_launch", "bytes_per_ray", "demand_GBps"))
     if "issue" in r:
         o["issue"] = _pick(r["issue"], ("bound", "frac", "active_lane_frac", "wait_frac", "frac_with_scalar"))
@@ -560,7 +565,7 @@ def _leg_short(leg):
     return o
 
 
-HEADLINE_MAX = 3600   # bytes: the driver keeps only the tail of stdout (round 2's 22 KB line came back as parsed = null)
+HEADLINE_MAX = 3900   # bytes: the driver keeps only the tail of stdout (round 2's 22 KB line came back as parsed = null)
 
 
 def headline(full, full_path):
