@@ -49,6 +49,28 @@ def _is_number(t):
         return False
 
 
+def _literal_kind(t):
+    """kind of one atomic literal as the reference's parser classifies it (scene_parsing/common.rs atomic_literal: a number, true /
+    false, or a quoted string; a bare word is an error, common.rs:650-654)"""
+    if t.startswith('"'):
+        return "str"
+    if t in ("true", "false"):
+        return "bool"
+    if _is_number(t):
+        return "num"
+    raise PbrtSceneError(f"{t} is not a literal (number, true / false or a quoted string)")
+
+
+def _check_values(typ, pname, vals):
+    """an array literal holds literals of ONE kind (common.rs literal_err_mixed_array); "rgb" takes exactly three numbers
+    (common.rs rgb_param_wrong_length)"""
+    kinds = {_literal_kind(v) for v in vals}
+    if len(kinds) > 1:
+        raise PbrtSceneError(f'parameter "{typ} {pname}": array literal mixes {" and ".join(sorted(kinds))}')
+    if typ == "rgb" and (kinds != {"num"} or len(vals) != 3):
+        raise PbrtSceneError(f'parameter "rgb {pname}" needs exactly 3 numbers')
+
+
 def _parse(text):
     """-> list of (directive, positional args, {param name: (type, values)})"""
     toks = list(_tokens(text))
@@ -72,8 +94,11 @@ def _parse(text):
                         i += 1
                     i += 1
                 else:
+                    if i >= len(toks):
+                        raise PbrtSceneError(f'parameter "{typ} {pname}" has no value')
                     vals.append(toks[i])
                     i += 1
+                _check_values(typ, pname, vals)
                 params[pname] = (typ, vals)
             elif t.startswith('"') or _is_number(t):
                 args.append(t.strip('"') if t.startswith('"') else float(t))
@@ -162,7 +187,14 @@ def load_pbrt(text, spectra=None):
             return tex
         raise PbrtSceneError(f'unsupported spectrum parameter "{typ} {name}"')
 
+    seen_options = set()
     for name, args, p in _parse(text):
+        if name in ("Camera", "Sampler", "ColorSpace", "Film", "PixelFilter", "Filter", "Integrator", "Accelerator"):
+            # scene_parsing/scene.rs:119-175: each of the options section's directives may appear once (RepeatedDirective;
+            # the reference's test_global_options_fail_on_repeat_directive)
+            if name in seen_options:
+                raise PbrtSceneError(f"repeated directive {name}")
+            seen_options.add(name)
         if name == "LookAt":
             if len(args) != 9:
                 raise PbrtSceneError("LookAt needs 9 numbers")

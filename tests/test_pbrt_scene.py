@@ -63,6 +63,8 @@ def test_directives_and_errors(pm):
                      ('Film "gbuffer"', "RGBFilm"), ("MakeNamedMedium \"fog\"", "not supported"),
                      ("AttributeEnd", "without")):
         text = head + bad + ('\nShape "sphere"' if bad.startswith("Material") else "")
+        if bad.startswith("Film"):          # (a second Film directive is an error of its own: "repeated directive", as upstream)
+            text = bad + "\n" + head
         with pytest.raises(pm.pbrt_scene.PbrtSceneError) as e:
             L(text)
         if msg:
