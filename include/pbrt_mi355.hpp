@@ -132,6 +132,13 @@ public:
         pmh_rgb_spectrum_table(c.data(), scale, d65.data(), out.data());
         return out;
     }
+    // PiecewiseLinearSpectrum::from_interleaved({lambda0, v0, lambda1, v1, ...}, normalize) densified (sampling/spectrum.rs:269-310)
+    std::vector<float> piecewise_linear_table(const std::vector<float>& interleaved, bool normalize = false) const {
+        std::vector<float> out(471);
+        if (pmh_piecewise_linear_table(interleaved.data(), (int)interleaved.size(), normalize ? 1 : 0, cie_y.data(), out.data()) != 0)
+            throw Error("piecewise-linear spectrum: an even, non-zero number of values with strictly ascending wavelengths is required");
+        return out;
+    }
     std::vector<float> blackbody_table(float kelvin) const { std::vector<float> out(471); pmh_blackbody_table(kelvin, out.data()); return out; }
     // PixelSensor::with_xyz_matching: r_bar, g_bar, b_bar = X, Y, Z
     std::vector<float> sensor_xyz_tables() const {

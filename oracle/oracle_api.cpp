@@ -628,6 +628,7 @@ int ora_host_gaussian_filter_table(float rx, float ry, float sigma, float* vals,
     if (vals) { if ((int)v.size() > cap) return 1; std::memcpy(vals, v.data(), v.size() * sizeof(float)); }
     return 0;
 }
+void ora_host_piecewise_linear_table(const float* il, int n, int normalize, const float* cie_y471, float* out471) { host::piecewise_linear_dense(il, n, normalize != 0, cie_y471, out471); }
 void ora_host_d65_table(const float* cie_y471, const float* d65_interleaved, int n, float* out471) { host::d65_dense(cie_y471, d65_interleaved, n, out471); }
 float ora_host_photometric(const float* cie_y471, const float* table471) { return host::photometric(cie_y471, table471); }
 float ora_host_blackbody_table(float temp, float* out471) { return host::blackbody_dense(temp, out471); }

@@ -182,6 +182,17 @@ static inline void d65_dense(const float* cie_y471, const float* il, int n_float
     for (auto& e : s) e.value *= k;
     for (int i = 0; i <= 470; ++i) out471[i] = pl_at(s, (float)(360 + i));
 }
+// PiecewiseLinearSpectrum::from_interleaved(.., normalize) densified (spectrum.rs:196-214,269-310)
+static inline void piecewise_linear_dense(const float* il, int n_floats, bool normalize, const float* cie_y471, float* out471) {
+    std::vector<PLSample> s = from_interleaved(il, n_floats);
+    if (normalize) {
+        float integral = 0.0f;
+        for (int i = 0; i <= 470; ++i) integral += pl_at(s, 360.0f + (float)i) * cie_y471[i];
+        const float k = CIE_Y_INTEGRAL / integral;
+        for (auto& e : s) e.value *= k;
+    }
+    for (int i = 0; i <= 470; ++i) out471[i] = pl_at(s, (float)(360 + i));
+}
 // spectrum.rs:152-160
 static inline float photometric(const float* cie_y471, const float* table471) {
     float y = 0.0f;

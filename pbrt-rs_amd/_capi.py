@@ -148,6 +148,7 @@ SYMBOLS = {
     "pmh_gaussian": (C.c_float, [C.c_float, C.c_float, C.c_float]),
     "pmh_fast_exp": (C.c_float, [C.c_float]),
     "pmh_d65_table": (None, [_P, _P, C.c_int, _P]),
+    "pmh_piecewise_linear_table": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "pmh_photometric": (C.c_float, [_P, _P]),
     "pmh_blackbody_table": (C.c_float, [C.c_float, _P]),
     "pmh_rgb_spectrum_table": (None, [_P, C.c_float, _P, _P]),

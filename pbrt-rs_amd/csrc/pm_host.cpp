@@ -195,13 +195,17 @@ int pmh_gaussian_filter_table(float rx, float ry, float sigma, float* vals, int 
 float pmh_gaussian(float x, float mean, float sd) { return gaussian(x, mean, sd); }
 float pmh_fast_exp(float x) { return fast_exp(x); }
 
-// ILLUMD65 (sampling/spectrum.rs:64-65,269-310) densified at 360..830 (DenselySampledSpectrum::new, :196-214)
-void pmh_d65_table(const float* cie_y471, const float* d65_interleaved, int n_interleaved, float* out471) {
-    int n = n_interleaved / 2;
+// PiecewiseLinearSpectrum::from_interleaved(samples, normalize) (sampling/spectrum.rs:269-310) densified at 360..830
+// (DenselySampledSpectrum::new, :196-214; PiecewiseLinearSpectrum::at, :331-357).  Nonzero: the input upstream asserts on
+// (an odd or zero count, wavelengths not strictly ascending).
+int pmh_piecewise_linear_table(const float* interleaved, int n_floats, int normalize, const float* cie_y471, float* out471) {
+    if (!interleaved || !out471 || n_floats < 2 || (n_floats % 2) != 0 || (normalize && !cie_y471)) return 1;
+    int n = n_floats / 2;
     std::vector<float> lam, val;
-    if (d65_interleaved[0] > 360.0f) { lam.push_back(359.0f); val.push_back(d65_interleaved[1]); }
-    for (int i = 0; i < n; ++i) { lam.push_back(d65_interleaved[2 * i]); val.push_back(d65_interleaved[2 * i + 1]); }
+    if (interleaved[0] > 360.0f) { lam.push_back(359.0f); val.push_back(interleaved[1]); }
+    for (int i = 0; i < n; ++i) { lam.push_back(interleaved[2 * i]); val.push_back(interleaved[2 * i + 1]); }
     if (lam.back() < 830.0f) { lam.push_back(831.0f); val.push_back(val.back()); }
+    for (size_t i = 1; i < lam.size(); ++i) if (!(lam[i - 1] < lam[i])) return 2;        // PiecewiseLinearSpectrum::new's assert
     auto at = [&](float l) {
         if (l < lam.front() || l > lam.back()) return 0.0f;
         int sz = (int)lam.size(), left = 0, right = sz - 1;     // find_interval(|i| lam[i] <= l)
@@ -211,11 +215,18 @@ void pmh_d65_table(const float* cie_y471, const float* d65_interleaved, int n_in
         float t = (l - lam[i]) / (lam[i + 1] - lam[i]);
         return lerpf(val[i], val[i + 1], t);
     };
-    float integral = 0.0f;
-    for (int l = 360; l <= 830; ++l) integral += at((float)l) * cie_y471[l - 360];
-    float s = 106.856895f / integral;
-    for (auto& v : val) v *= s;
+    if (normalize) {            // to luminance 1: CIE_Y_INTEGRAL / inner_product(Y)
+        float integral = 0.0f;
+        for (int l = 360; l <= 830; ++l) integral += at((float)l) * cie_y471[l - 360];
+        float s = 106.856895f / integral;
+        for (auto& v : val) v *= s;
+    }
     for (int l = 360; l <= 830; ++l) out471[l - 360] = at((float)l);
+    return 0;
+}
+// ILLUMD65 (sampling/spectrum.rs:64-65): from_interleaved(.., normalize = true)
+void pmh_d65_table(const float* cie_y471, const float* d65_interleaved, int n_interleaved, float* out471) {
+    (void)pmh_piecewise_linear_table(d65_interleaved, n_interleaved, 1, cie_y471, out471);
 }
 // Spectrum::to_photometric (sampling/spectrum.rs:152-160)
 float pmh_photometric(const float* cie_y471, const float* table471) {

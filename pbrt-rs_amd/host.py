@@ -168,6 +168,15 @@ class Spectra:
     def constant_table(self, c):
         return np.full(471, c, np.float32)
 
+    def piecewise_linear_table(self, interleaved, normalize=False):
+        """PiecewiseLinearSpectrum::from_interleaved([lambda0, v0, lambda1, v1, ...], normalize) densified at 360..830 nm
+        (sampling/spectrum.rs:269-310); ValueError for what upstream asserts on"""
+        il = _f32(interleaved).reshape(-1)
+        out = np.zeros(471, np.float32)
+        if _capi.lib().pmh_piecewise_linear_table(_p(il), len(il), int(bool(normalize)), _p(self.cie_y), _p(out)) != 0:
+            raise ValueError("piecewise-linear spectrum: an even, non-zero number of values with strictly ascending wavelengths is required")
+        return out
+
     def sensor_xyz_tables(self):
         """PixelSensor::with_xyz_matching: r_bar, g_bar, b_bar = X, Y, Z (camera/sensor.rs:85-111)"""
         return np.ascontiguousarray(np.concatenate([self.cie_x, self.cie_y, self.cie_z]).astype(np.float32))

@@ -16,7 +16,8 @@ where the reference has none yet):
 Substitutions are made LOUDLY: every one is appended to settings["warnings"] (the reference has one sampler and no
 MIS / volumetric integrator): Sampler "halton"/"sobol"/... -> independent (same pixelsamples and seed);
 Integrator "path" -> simplepath; "volpath" -> VolPath, which without a medium in the file equals simplepath.
-Spectrum-valued parameters: "rgb X" [r g b], "blackbody X" T, "float X" v, "spectrum X" v (constant).
+Spectrum-valued parameters: "rgb X" [r g b], "blackbody X" T, "float X" v, "spectrum X" v (constant),
+"spectrum X" [lambda0 v0 lambda1 v1 ...] (PiecewiseLinearSpectrum::from_interleaved, sampling/spectrum.rs:269-310).
 Anything else raises PbrtSceneError naming the directive: nothing is silently dropped.
 """
 import re
@@ -180,6 +181,12 @@ def load_pbrt(text, spectra=None):
             return ("blackbody", np.float32(vals[0]))
         if typ in ("float", "spectrum") and len(vals) == 1 and _is_number(vals[0]):
             return ("const", np.float32(vals[0]))
+        if typ == "spectrum" and len(vals) >= 2 and len(vals) % 2 == 0 and all(_is_number(v) for v in vals):
+            # "spectrum X" [lambda0 v0 lambda1 v1 ...]: PiecewiseLinearSpectrum::from_interleaved(.., false), densified
+            try:
+                return ("table", sp.piecewise_linear_table([np.float32(v) for v in vals]))
+            except ValueError as e:
+                raise PbrtSceneError(f'parameter "spectrum {name}": {e}')
         if typ == "texture":
             tex = named_textures.get(vals[0].strip('"'))
             if tex is None:
@@ -310,6 +317,8 @@ def load_pbrt(text, spectra=None):
             return sp.rgb_illuminant_table(v)[0]
         if kind == "blackbody":
             return sp.blackbody_table(float(v))
+        if kind == "table":
+            return v.copy()
         return sp.constant_table(float(v))
 
     for kind, p, ctm in pending_lights:
@@ -358,7 +367,9 @@ def load_pbrt(text, spectra=None):
                     return sp.rgb_albedo(s[1])
                 if s[0] == "const":
                     return host.constant_spectrum(float(s[1]))
-                raise PbrtSceneError("diffuse reflectance must be rgb, a constant, or a checkerboard of those")
+                if s[0] == "table":
+                    return host.dense_spectrum(s[1])
+                raise PbrtSceneError("diffuse reflectance must be rgb, a constant, a sampled spectrum, or a checkerboard of those")
             if spec[0] == "checker":
                 t1, t2, su, sv, du, dv = spec[1]
                 m = host.checkerboard_diffuse(albedo(t1), albedo(t2), float(su), float(sv), float(du), float(dv))
@@ -366,10 +377,11 @@ def load_pbrt(text, spectra=None):
                 m = host.diffuse(albedo(spec))
         elif kind == "dielectric":
             eta = spectrum_param(p, "eta") or ("const", f32(1.5))
-            if eta[0] != "const":
-                raise PbrtSceneError("dielectric eta must be a constant")
+            if eta[0] not in ("const", "table"):
+                raise PbrtSceneError("dielectric eta must be a constant or a sampled spectrum")
             r = _float(p, "roughness", 0.0)
-            m = host.dielectric(host.constant_spectrum(float(eta[1])), float(_float(p, "uroughness", r)),
+            eta_spec = host.constant_spectrum(float(eta[1])) if eta[0] == "const" else host.dense_spectrum(eta[1])
+            m = host.dielectric(eta_spec, float(_float(p, "uroughness", r)),
                                 float(_float(p, "vroughness", r)), _bool(p, "remaproughness", True))
         else:
             raise PbrtSceneError(f'Material "{kind}" is not supported (the reference has diffuse and dielectric)')
