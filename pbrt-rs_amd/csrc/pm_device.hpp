@@ -483,7 +483,10 @@ struct SlowWriter {
 #ifndef PM_PEND_ANY
 #define PM_PEND_ANY 1          /* park leaves in the any-hit walk too */
 #endif
-#define PM_CAND_WORDS(ANY, COUNT, KIND) (2 * PM_CAND_MAX + (((ANY) && !PM_PEND_ANY) || (COUNT) || (KIND) == PM_WALK_MIXED ? 0 : PM_PEND_MAX))
+#ifndef PM_PEND_MIXED
+#define PM_PEND_MIXED 1        /* round 3: the MIXED walk parks its triangle and patch leaves too (spheres stay in the node step) */
+#endif
+#define PM_CAND_WORDS(ANY, COUNT, KIND) (2 * PM_CAND_MAX + (((ANY) && !PM_PEND_ANY) || (COUNT) || ((KIND) == PM_WALK_MIXED && !PM_PEND_MIXED) ? 0 : PM_PEND_MAX))
 // what a walk kernel is compiled for (template argument KIND of trace_persistent; `false` / `true` still mean TRI / MIXED)
 #define PM_WALK_TRI 0        /* the scene holds triangles only */
 #define PM_WALK_MIXED 1      /* spheres, or several primitive types: no parked leaves; spheres deferred to the second pass */
@@ -512,6 +515,42 @@ struct SlowWriter {
 PMD float safe_rcp_dir(float d) { return fabsf(d) < 1e-18f ? copysignf(1e18f, d) : 1.0f / d; }
 #define PM_NODE_MARGIN 2.384185791015625e-07f   /* 4 * 2^-24: rounding of the pre-scaled slab evaluation */
 #define PM_WALK_GUARD (1u << 22)                /* per-ray bound on node steps (a corrupt buffer cannot hang a wave) */
+
+// The interval-arithmetic sphere test + (u, v) of sphere.rs:382-385 for the record at r, as a real (not inlined) function: the
+// MIXED walk reaches it only for a third sphere of one ray and in the fallback walk.
+__device__ __noinline__ bool sphere_test_cold(const uint4* __restrict__ r, f3 ro, f3 rd, float t_max, float* to, float* uo, float* vo,
+                                              uint32_t* ido) {
+    float m[12];
+    const uint4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+    m[0] = __uint_as_float(r0.x); m[1] = __uint_as_float(r0.y); m[2] = __uint_as_float(r0.z); m[3] = __uint_as_float(r0.w);
+    m[4] = __uint_as_float(r1.x); m[5] = __uint_as_float(r1.y); m[6] = __uint_as_float(r1.z); m[7] = __uint_as_float(r1.w);
+    m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
+    const float radius = __uint_as_float(r3.x), zmin = __uint_as_float(r3.y), zmax = __uint_as_float(r3.z), phimax = __uint_as_float(r3.w);
+    SphereHit sh;
+    if (!intersect_sphere(ro, rd, t_max, m, radius, zmin, zmax, phimax, &sh)) return false;
+    const float th0 = acosf(fminf(fmaxf(zmin / radius, -1.0f), 1.0f));
+    const float th1 = acosf(fminf(fmaxf(zmax / radius, -1.0f), 1.0f));
+    const float th = acosf(fminf(fmaxf(sh.p_obj.z / radius, -1.0f), 1.0f));
+    *to = sh.t; *uo = sh.phi / phimax; *vo = (th - th0) / (th1 - th0); *ido = r4.x;
+    return true;
+}
+
+// The reference-arithmetic test of the patch record (or of the triangle record, as the degenerate patch) at r, as a real function
+// for the MIXED walk (PM_MIXED_COLD_PATCH): result (t, u, v, id bits), t = INFINITY for "no hit within t_max".
+__device__ __noinline__ float4 patch_test_cold(const uint4* __restrict__ r, int is_tri, f3 ro, f3 rd, float t_max) {
+    const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
+    const f3 p00 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
+    const f3 p10 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
+    const f3 p01 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
+    f3 p11 = p01; uint32_t id = r2.y;
+    if (!is_tri) { const uint4 r3 = r[3]; p11 = mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w)); id = r3.x; }
+    float t, u, v;
+    if (!intersect_patch(ro, rd, t_max, p00, p10, p01, p11, &t, &u, &v)) return make_float4(INFINITY, 0.0f, 0.0f, __uint_as_float(id));
+    return make_float4(t, u, v, __uint_as_float(id));
+}
+#ifndef PM_MIXED_COLD_PATCH
+#define PM_MIXED_COLD_PATCH 1
+#endif
 
 // Rays through the wide BVH, persistent waves.  ANY: intersect_p (is anything hit before ray.tmax); otherwise closest hit.
 //
@@ -564,10 +603,10 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
     bool sure_any = false;
 #define PM_SURE (ANY ? sure_any : (tcull < ray.tmax))
     uint32_t qn = 0;
-    constexpr bool DEFERL = PM_PEND_MAX > 0 && (PM_PEND_ANY || !ANY) && !COUNT && !MIXED;
+    constexpr bool DEFERL = PM_PEND_MAX > 0 && (PM_PEND_ANY || !ANY) && !COUNT && (!MIXED || PM_PEND_MIXED);
     // Pooled exact tests (closest hit, triangle-only scenes): see the refill phase.  The finished lanes' candidates are
     // dealt out over ALL lanes of the wave, one (ray, triangle) pair each.
-    constexpr bool POOL = PM_POOL_EXACT && !ANY && KIND == PM_WALK_TRI && PM_LDS_STACK >= 6 && PM_CAND_MAX == 4;
+    constexpr bool POOL = PM_POOL_EXACT && !ANY && (KIND == PM_WALK_TRI || (MIXED && DEFERL)) && PM_LDS_STACK >= 6 && PM_CAND_MAX == 4;
     __shared__ uint8_t pool_pairs[(POOL ? 4 : 1) * 64];        // per wave: (owner lane << 2 | candidate) of the pairs in flight
     uint8_t* const my_pairs = pool_pairs + (POOL ? (threadIdx.x >> 6) * 64u : 0u);
     uint2* const lds_w = lds - lane;                           // the wave's base of the strided per-lane arrays
@@ -603,15 +642,23 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
     };
     // pre-filter of one parked triangle (DEFERL): the triangle branch of the leaf loop below, for a unit popped from the ring
     auto drain_one = [&]() {
-        const uint32_t unit = cand[(2 * PM_CAND_MAX + (ph & (PM_PEND_MAX > 0 ? PM_PEND_MAX - 1 : 0))) * stride];
+        const uint32_t tagged = cand[(2 * PM_CAND_MAX + (ph & (PM_PEND_MAX > 0 ? PM_PEND_MAX - 1 : 0))) * stride];
         ++ph; --np;
+        // (MIXED: the ring entry carries the leaf's primitive type above the 30-bit record unit)
+        const uint32_t unit = MIXED ? (tagged & 0x3FFFFFFFu) : tagged;
+        const bool parked_patch = PONLY || (MIXED && (tagged >> 30) == PM_PRIM_PATCH);
         const uint4* r = prims + unit;
         const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
         const f3 p00 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
         const f3 p10 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
         const f3 p01 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
-        if (PONLY) {        // a parked PATCH: the reference arithmetic now, with whoever else has one parked (no float pre-filter
+        if (parked_patch) { // a parked PATCH: the reference arithmetic now, with whoever else has one parked (no float pre-filter
                             // exists for the bilinear test; its box test was the node step's - the leaf's own quantised box)
+            if (MIXED && PM_MIXED_COLD_PATCH) {
+                const float4 h = patch_test_cold(r, 0, ray.o, ray.d, tie_tmax());
+                if (h.x < INFINITY && tri_take(h.x, h.y, h.z, __float_as_uint(h.w))) tcull = fminf(tcull, h.x);
+                return;
+            }
             const uint4 r3 = r[3];
             const f3 p11 = mk3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
             float t, u, v;
@@ -627,7 +674,12 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                 ++qn;
             } else {                                  // candidate queue full: the exact test at once
                 float t, u, v;
-                if (intersect_tri_exact(ray.o, ray.d, tie_tmax(), p00, p10, p01, &t, &u, &v)) (void)tri_take(t, u, v, r2.y);
+                if (MIXED && PM_MIXED_COLD_PATCH) {
+                    const float4 h = patch_test_cold(r, 1, ray.o, ray.d, tie_tmax());
+                    if (h.x < INFINITY) (void)tri_take(h.x, h.y, h.z, __float_as_uint(h.w));
+                } else if (MIXED) {    // (the MIXED kernels reach the triangle test through the patch code they carry anyway)
+                    if (intersect_patch(ray.o, ray.d, tie_tmax(), p00, p10, p01, p01, &t, &u, &v)) (void)tri_take(t, u, v, r2.y);
+                } else if (intersect_tri_exact(ray.o, ray.d, tie_tmax(), p00, p10, p01, &t, &u, &v)) (void)tri_take(t, u, v, r2.y);
             }
         }
     };
@@ -879,8 +931,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                             m[0] = __uint_as_float(r0.x); m[1] = __uint_as_float(r0.y); m[2] = __uint_as_float(r0.z); m[3] = __uint_as_float(r0.w);
                             m[4] = __uint_as_float(r1.x); m[5] = __uint_as_float(r1.y); m[6] = __uint_as_float(r1.z); m[7] = __uint_as_float(r1.w);
                             m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
-                            const float radius = __uint_as_float(r3.x), zmin = __uint_as_float(r3.y), zmax = __uint_as_float(r3.z),
-                                        phimax = __uint_as_float(r3.w);
+                            const float radius = __uint_as_float(r3.x);
                             if (!exact_mode) {
                                 if (!sphere_prefilter(ray.o, ray.d, R, D, m, radius, __uint_as_float(r4.z), __uint_as_float(r4.w), tcull))
                                     continue;
@@ -889,21 +940,18 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                                 if (sph1 == 0xFFFFFFFFu) { sph1 = unit; continue; }
                             }                       // a third sphere for the same ray is tested at once
                             if (COUNT) ctr->exact++;
-                            SphereHit sh;
-                            if (intersect_sphere(ray.o, ray.d, tmax, m, radius, zmin, zmax, phimax, &sh)) {
-                                tmax = sh.t; tcull = fminf(tcull, sh.t); found = true; hit.prim_id = r4.x; hit.t = sh.t;
-                                // (u,v) of sphere.rs:382-385
-                                const float th0 = acosf(fminf(fmaxf(zmin / radius, -1.0f), 1.0f));
-                                const float th1 = acosf(fminf(fmaxf(zmax / radius, -1.0f), 1.0f));
-                                const float th = acosf(fminf(fmaxf(sh.p_obj.z / radius, -1.0f), 1.0f));
-                                hit.u = sh.phi / phimax; hit.v = (th - th0) / (th1 - th0);
+                            // (rare: a third sphere of one ray, or the fallback walk.  Out of line, so that the interval
+                            // arithmetic's ~90 live values are the callee's registers and not the node step's)
+                            float st, su, sv; uint32_t sid;
+                            if (sphere_test_cold(r, ray.o, ray.d, tmax, &st, &su, &sv, &sid)) {
+                                tmax = st; tcull = fminf(tcull, st); found = true; hit.prim_id = sid; hit.t = st; hit.u = su; hit.v = sv;
                             }
                         } else {
                             // triangle record: v0 v1 v2 id ; patch record: p00 p10 p01 p11 id
                             const bool is_tri = ptype == PM_PRIM_TRI;
                             const uint32_t unit = pbase + (off + j) * (is_tri ? PM_UNITS_TRI : PM_UNITS_PATCH);
                             if (DEFERL && !exact_mode && np < PM_PEND_MAX) {        // park it (triangle-only scene)
-                                cand[(2 * PM_CAND_MAX + ((ph + np) & (PM_PEND_MAX > 0 ? PM_PEND_MAX - 1 : 0))) * stride] = unit;
+                                cand[(2 * PM_CAND_MAX + ((ph + np) & (PM_PEND_MAX > 0 ? PM_PEND_MAX - 1 : 0))) * stride] = MIXED ? (unit | (ptype << 30)) : unit;
                                 ++np;
                                 continue;
                             }
@@ -942,7 +990,12 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                                 }
                                 if (COUNT) ctr->exact++;
                                 float t, u, v;
-                                if (is_tri) {
+                                if (MIXED && PM_MIXED_COLD_PATCH && !COUNT) {
+                                    const float4 h = patch_test_cold(r, is_tri ? 1 : 0, ray.o, ray.d, tie_tmax());
+                                    if (h.x < INFINITY && tri_take(h.x, h.y, h.z, __float_as_uint(h.w))) {
+                                        if (exact_mode || !is_tri) tcull = fminf(tcull, h.x);
+                                    }
+                                } else if (is_tri) {
                                     if (intersect_patch(ray.o, ray.d, tie_tmax(), p00, p10, p01, p11, &t, &u, &v) && tri_take(t, u, v, id)) {
                                         if (exact_mode) tcull = fminf(tcull, t);
                                     }
