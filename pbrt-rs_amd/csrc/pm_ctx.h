@@ -42,7 +42,10 @@ struct RenderState;   // pm_render.hip
 #define PM_MIXED_WAVES_PER_EU 4     // ... of scenes that hold spheres or patches as well: their walk carries more code, and 5
                                     // waves (96 VGPRs) spill into it (scripts/mixed_probe.py: 4 beats 5 by 39 %, 3 by 3 %)
 #endif
-#define PM_TRAV_WAVES(any, mixed) ((mixed) ? PM_MIXED_WAVES_PER_EU : (any) ? PM_ANY_WAVES_PER_EU : PM_WAVES_PER_EU)
+#ifndef PM_PATCH_WAVES_PER_EU
+#define PM_PATCH_WAVES_PER_EU 4     // ... of patch-only scenes (KIND == 2: 117 VGPRs with the bilinear test inlined)
+#endif
+#define PM_TRAV_WAVES(any, mixed) ((mixed) == 2 ? PM_PATCH_WAVES_PER_EU : (mixed) ? PM_MIXED_WAVES_PER_EU : (any) ? PM_ANY_WAVES_PER_EU : PM_WAVES_PER_EU)
 #define PM_TRAV_ATTR(any, mixed) __attribute__((amdgpu_waves_per_eu(PM_TRAV_WAVES(any, mixed), PM_TRAV_WAVES(any, mixed))))
 
 struct pm_ctx {

@@ -551,6 +551,9 @@ __device__ __noinline__ float4 patch_test_cold(const uint4* __restrict__ r, int 
 #ifndef PM_MIXED_COLD_PATCH
 #define PM_MIXED_COLD_PATCH 1
 #endif
+#ifndef PM_PATCH_COLD
+#define PM_PATCH_COLD 0         /* the same for the patch-only walk (measured, scripts/ab_lib.sh) */
+#endif
 
 // Rays through the wide BVH, persistent waves.  ANY: intersect_p (is anything hit before ray.tmax); otherwise closest hit.
 //
@@ -654,7 +657,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
         const f3 p01 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x));
         if (parked_patch) { // a parked PATCH: the reference arithmetic now, with whoever else has one parked (no float pre-filter
                             // exists for the bilinear test; its box test was the node step's - the leaf's own quantised box)
-            if (MIXED && PM_MIXED_COLD_PATCH) {
+            if ((MIXED && PM_MIXED_COLD_PATCH) || (PONLY && PM_PATCH_COLD)) {
                 const float4 h = patch_test_cold(r, 0, ray.o, ray.d, tie_tmax());
                 if (h.x < INFINITY && tri_take(h.x, h.y, h.z, __float_as_uint(h.w))) tcull = fminf(tcull, h.x);
                 return;
@@ -990,7 +993,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                                 }
                                 if (COUNT) ctr->exact++;
                                 float t, u, v;
-                                if (MIXED && PM_MIXED_COLD_PATCH && !COUNT) {
+                                if (((MIXED && PM_MIXED_COLD_PATCH) || (PONLY && PM_PATCH_COLD)) && !COUNT) {
                                     const float4 h = patch_test_cold(r, is_tri ? 1 : 0, ray.o, ray.d, tie_tmax());
                                     if (h.x < INFINITY && tri_take(h.x, h.y, h.z, __float_as_uint(h.w))) {
                                         if (exact_mode || !is_tri) tcull = fminf(tcull, h.x);
