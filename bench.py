@@ -330,9 +330,9 @@ def kernel_bytes(st, info, spp_rendered, ext):
         dem_s = st["shadow_nodes"] * node + st["shadow_prims"] * rec
     cont = C - S                                            # entries written into the next queue over all bounces
     b = [0.0] * 5
-    b[0] = S * (16 + 16 + 16 + 8 + 16 + 16 + 16 + 4)                     # ro rd beta rng | L lambda_s pdf fw
+    b[0] = S * (16 + 16 + 8 + 16 + 16 + 16 + 4)                          # ro rd rng | L lambda_s pdf fw (beta of a camera ray is 1: not stored)
     b[1] = C * (32 + 16)                                                 # ro rd in, hit out
-    b[2] = C * (16 + 16 + 16 + 8 + 16 + 16) + cont * (16 + 16 + 16 + 8) + SH * 48   # state, hit, lambda (by slot) in; survivors + shadow entries out
+    b[2] = C * (16 + 16 + 16 + 8 + 16 + 16) - S * 16 + cont * (16 + 16 + 16 + 8) + SH * 48   # state (no beta at the first bounce), hit, lambda (by slot) in; survivors + shadow entries out
     b[3] = SH * (48 + 32)                                                # shadow entry in; L read-modify-write (unoccluded: upper bound)
     b[4] = S * (16 + 16 + 16 + 4) + (S / max(1, spp_rendered)) * 64      # L lambda pdf fw in, film pixel RMW
     demand = list(b)

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(RB) void raygen_kernel(RenderConst rc, SceneArrays 
     generate_camera_ray(rc, pf, pl, &o, &d);
     pa.ro[0][slot] = with_w(o, slot);
     pa.rd[0][slot] = with_w(d, 0u | (1u << 8));                    // depth 0, specular_bounce = true
-    pa.beta[0][slot] = make_float4(1.f, 1.f, 1.f, 1.f);
+    // (beta of a camera ray is all ones: not written - shade_kernel knows the first bounce from bit 1 of its `g` argument)
     pa.rng[0][slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
     pa.L[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     pa.lambda_s[slot] = make_float4(lam[0], lam[1], lam[2], lam[3]);
@@ -507,9 +507,12 @@ __device__ __forceinline__ bool block_regroup(int* kind, uint32_t (&w)[PM_XCH_WO
 // Cornell box under a ceiling quad emitter.  The plain straight-line body plus emission on a hit and the shape-sampling branch of
 // sample_light; round 2 sent such scenes through the EXT kernel.
 template <bool EXT, bool AREA = false>
-__global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc, SceneArrays sc, PathArrays pa, uint32_t g,
+__global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc, SceneArrays sc, PathArrays pa, uint32_t g_first,
                                                    const uint32_t* __restrict__ count_in,
                                                    uint32_t* __restrict__ count_out, uint32_t* __restrict__ shadow_count) {
+    // g_first = generation of the path-state arrays | 2 for the first bounce of a pass (camera rays: beta = 1, never stored)
+    const uint32_t g = g_first & 1u;
+    const bool first = (g_first & 2u) != 0u;
     __shared__ uint32_t lds_ab[2 * (RB / 64 + 1)];
     const uint32_t i = blockIdx.x * RB + threadIdx.x;
     const uint32_t n_in = *count_in;
@@ -535,7 +538,8 @@ __global__ __launch_bounds__(RB) PM_SHADE_ATTR void shade_kernel(RenderConst rc,
     float4 rd4 = make_float4(0.f, 0.f, 0.f, __uint_as_float(PM_DEAD)), ro4 = rd4, hv = rd4, b4 = rd4;
     uint2 r2 = make_uint2(0u, 0u);
     if (live) {
-        rd4 = nt_load(pa.rd[g] + i); ro4 = nt_load(pa.ro[g] + i); hv = nt_load(pa.hit + i); b4 = nt_load(pa.beta[g] + i);
+        rd4 = nt_load(pa.rd[g] + i); ro4 = nt_load(pa.ro[g] + i); hv = nt_load(pa.hit + i);
+        b4 = first ? make_float4(1.f, 1.f, 1.f, 1.f) : nt_load(pa.beta[g] + i);
         r2 = pa.rng[g][i];
     }
     const uint32_t mw = __float_as_uint(rd4.w);
@@ -1602,10 +1606,10 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
             }
             mark(2);
             if (random_walk) hipLaunchKernelGGL(shade_rw_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out);
-            else if (r->have_sphere_lights) hipLaunchKernelGGL((shade_kernel<true, true>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out, cnt_sh);
-            else if (shade_ext || force_ext) hipLaunchKernelGGL((shade_kernel<true, false>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out, cnt_sh);
-            else if (shade_area) hipLaunchKernelGGL((shade_kernel<false, true>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out, cnt_sh);
-            else hipLaunchKernelGGL((shade_kernel<false, false>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out, cnt_sh);
+            else if (r->have_sphere_lights) hipLaunchKernelGGL((shade_kernel<true, true>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen | (b == 0 ? 2u : 0u), cnt_in, cnt_out, cnt_sh);
+            else if (shade_ext || force_ext) hipLaunchKernelGGL((shade_kernel<true, false>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen | (b == 0 ? 2u : 0u), cnt_in, cnt_out, cnt_sh);
+            else if (shade_area) hipLaunchKernelGGL((shade_kernel<false, true>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen | (b == 0 ? 2u : 0u), cnt_in, cnt_out, cnt_sh);
+            else hipLaunchKernelGGL((shade_kernel<false, false>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen | (b == 0 ? 2u : 0u), cnt_in, cnt_out, cnt_sh);
             if (!random_walk && p->sample_lights && b < p->max_depth) {
                 mark(3);
                 if (flat) {
