@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <limits>
@@ -41,6 +42,18 @@ struct BinBuilder {
     std::vector<float> cen;           // centroids, 3 per prim
     std::vector<uint32_t>& order;     // permutation being partitioned
     int max_leaf;
+    // unified build over several primitive types (round 3): a leaf holds primitives of ONE type, at most max_leaf_of[type] of them
+    const std::vector<uint8_t>* types = nullptr;
+    int max_leaf_of[3] = {0, 0, 0};
+    // may order[lo, hi) become a leaf?
+    bool leaf_ok(uint32_t lo, uint32_t hi) const {
+        const uint32_t n = hi - lo;
+        if (!types) return n <= (uint32_t)max_leaf;
+        const uint8_t t = (*types)[order[lo]];
+        if (n > (uint32_t)max_leaf_of[t]) return false;
+        for (uint32_t i = lo + 1; i < hi; ++i) if ((*types)[order[i]] != t) return false;
+        return true;
+    }
     BinBuilder(const std::vector<Box>& b, std::vector<uint32_t>& o, int ml) : pb(b), order(o), max_leaf(ml) {
         cen.resize(b.size() * 3);
         for (size_t i = 0; i < b.size(); ++i)
@@ -95,14 +108,14 @@ struct BinBuilder {
             if (best_i >= 0) {
                 float leaf_cost = (float)n * box_area(nd.b);
                 // traversal cost 1 node ~ 1 prim test; only keep a leaf when it is small enough and cheaper
-                if (n <= (uint32_t)max_leaf && leaf_cost <= best + box_area(nd.b)) return make_leaf();
+                if (leaf_ok(lo, hi) && leaf_cost <= best + box_area(nd.b)) return make_leaf();
                 auto it = std::partition(order.begin() + lo, order.begin() + hi, [&](uint32_t p) { return bin_of(p) <= best_i; });
                 mid = (uint32_t)(it - order.begin());
                 split_done = mid > lo && mid < hi;
             }
         }
         if (!split_done) {
-            if (n <= (uint32_t)max_leaf) return make_leaf();
+            if (leaf_ok(lo, hi)) return make_leaf();
             mid = lo + n / 2;   // coincident centroids: split the index range
             std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi,
                              [&](uint32_t a, uint32_t b) { return cen[3 * a + dim] < cen[3 * b + dim]; });
@@ -171,21 +184,26 @@ static void quantise_node(PmWideNode& wn, const Box& nb, const Box* cb, const bo
 
 struct Collapser {
     const std::vector<BinNode>& bn;
-    const std::vector<uint32_t>& order;   // local prim order of this type
-    int type;
+    const std::vector<uint32_t>& order;   // local prim order of this tree
+    int type;                             // primitive type of the whole tree, or ...
     Accel& acc;
     const HostScene& sc;
-    const std::vector<uint32_t>& local_to_global;   // local prim index -> index into per-type arrays
+    const std::vector<uint32_t>& local_to_global;   // local prim index -> index into the per-type array of its type
+    const std::vector<uint8_t>* types = nullptr;    // ... (unified tree) the type of every local prim
+
+    int type_of(uint32_t local) const { return types ? (int)(*types)[local] : type; }
+    int leaf_type(int b) const { return type_of(order[bn[b].first]); }      // (leaves hold one type)
 
     void emit_record(uint32_t local) {
         uint32_t gi = local_to_global[local];
-        if (type == PM_PRIM_TRI) {
+        const int ty = type_of(local);
+        if (ty == PM_PRIM_TRI) {
             PmTriRecord r{};
             const HostTri& t = sc.tris[gi];
             std::memcpy(r.v0, t.v[0], 12); std::memcpy(r.v1, t.v[1], 12); std::memcpy(r.v2, t.v[2], 12);
             r.prim_id = t.prim_id;
             size_t off = acc.prims.size(); acc.prims.resize(off + sizeof(r)); std::memcpy(&acc.prims[off], &r, sizeof(r));
-        } else if (type == PM_PRIM_PATCH) {
+        } else if (ty == PM_PRIM_PATCH) {
             PmPatchRecord r{};
             const HostPatch& p = sc.patches[gi];
             std::memcpy(r.p00, p.p[0], 12); std::memcpy(r.p10, p.p[1], 12); std::memcpy(r.p01, p.p[2], 12); std::memcpy(r.p11, p.p[3], 12);
@@ -207,83 +225,129 @@ struct Collapser {
         }
     }
 
-    // Fill wide node `wi` from binary subtree rooted at `b`; queue gets (wide index, binary index) of interior children.
-    void fill(uint32_t wi, int b, std::vector<std::pair<uint32_t, int>>& queue) {
+    // One unit of work: fill wide node `wide` from the binary subtree rooted at `bin`, or - unified tree only - from a GROUP of
+    // binary leaves of one type (`leaves`), see fill().
+    struct Work { uint32_t wide; int bin; std::vector<int> leaves; };
+    // a child of the wide node being filled: a binary node (interior or leaf), or a group of leaves that gets a node of its own
+    struct Child { Box b; int bin; std::vector<int> group; bool interior() const { return !group.empty() || bin_interior; } bool bin_interior; };
+
+    void fill(const Work& w, std::vector<Work>& queue) {
         int kids[8]; int nk = 0;
-        if (bn[b].left < 0) { kids[nk++] = b; }
-        else { kids[nk++] = bn[b].left; kids[nk++] = bn[b].right; }
-        // greedy expansion: open the interior child with the largest surface area
-        for (;;) {
-            if (nk >= 8) break;
-            int best = -1; float ba = -1.0f;
-            for (int i = 0; i < nk; ++i)
-                if (bn[kids[i]].left >= 0) { float a = box_area(bn[kids[i]].b); if (a > ba) { ba = a; best = i; } }
-            if (best < 0) break;
-            int k = kids[best];
-            kids[best] = bn[k].left; kids[nk++] = bn[k].right;
+        Box nb;
+        if (!w.leaves.empty()) {            // a group: its leaves are the children, nothing to expand
+            nb = box_empty();
+            for (int l : w.leaves) { kids[nk++] = l; nb = box_union(nb, bn[l].b); }
+        } else {
+            const int b = w.bin;
+            nb = bn[b].b;
+            if (bn[b].left < 0) { kids[nk++] = b; }
+            else { kids[nk++] = bn[b].left; kids[nk++] = bn[b].right; }
+            // greedy expansion: open the interior child with the largest surface area
+            for (;;) {
+                if (nk >= 8) break;
+                int best = -1; float ba = -1.0f;
+                for (int i = 0; i < nk; ++i)
+                    if (bn[kids[i]].left >= 0) { float a = box_area(bn[kids[i]].b); if (a > ba) { ba = a; best = i; } }
+                if (best < 0) break;
+                int k = kids[best];
+                kids[best] = bn[k].left; kids[nk++] = bn[k].right;
+            }
         }
+        // A wide node has ONE record array, i.e. its leaves share a primitive type.  In a unified tree over several types the
+        // leaves of the type most of them have stay leaves of this node; the leaves of every other type move, together, into a
+        // node of their own one level down (a Work item with `leaves`): one more node step for them, in exchange for ONE tree
+        // that follows the geometry instead of one tree per type that every ray has to walk.
+        int node_type = type;
+        std::vector<Child> ch;
+        if (types) {
+            int n_of[3] = {0, 0, 0};
+            for (int i = 0; i < nk; ++i) if (bn[kids[i]].left < 0) n_of[leaf_type(kids[i])]++;
+            node_type = 0;
+            for (int t = 1; t < 3; ++t) if (n_of[t] > n_of[node_type]) node_type = t;
+            std::vector<int> minority[3];
+            for (int i = 0; i < nk; ++i) {
+                const int k = kids[i];
+                if (bn[k].left < 0 && leaf_type(k) != node_type) minority[leaf_type(k)].push_back(k);
+                else ch.push_back(Child{bn[k].b, k, {}, bn[k].left >= 0});
+            }
+            for (int t = 0; t < 3; ++t) {
+                if (minority[t].empty()) continue;
+                Box gb = box_empty();
+                for (int l : minority[t]) gb = box_union(gb, bn[l].b);
+                ch.push_back(Child{gb, -1, minority[t], false});
+            }
+        } else {
+            for (int i = 0; i < nk; ++i) ch.push_back(Child{bn[kids[i]].b, kids[i], {}, bn[kids[i]].left >= 0});
+        }
+        const int nc = (int)ch.size();
         // octant slot assignment: maximise dot(child centroid - node centroid, slot direction), greedily
-        const Box& nb = bn[b].b;
         float pc[3] = {0.5f * (nb.lo[0] + nb.hi[0]), 0.5f * (nb.lo[1] + nb.hi[1]), 0.5f * (nb.lo[2] + nb.hi[2])};
         float cost[8][8];
-        for (int i = 0; i < nk; ++i) {
-            const Box& cbx = bn[kids[i]].b;
+        for (int i = 0; i < nc; ++i) {
+            const Box& cbx = ch[i].b;
             float d[3] = {0.5f * (cbx.lo[0] + cbx.hi[0]) - pc[0], 0.5f * (cbx.lo[1] + cbx.hi[1]) - pc[1], 0.5f * (cbx.lo[2] + cbx.hi[2]) - pc[2]};
             for (int s = 0; s < 8; ++s)
                 cost[i][s] = ((s & 1) ? d[0] : -d[0]) + ((s & 2) ? d[1] : -d[1]) + ((s & 4) ? d[2] : -d[2]);
         }
         int slot_of[8]; bool child_done[8] = {false}, slot_used[8] = {false};
-        for (int it = 0; it < nk; ++it) {
+        for (int it = 0; it < nc; ++it) {
             int bi = -1, bs = -1; float bc = -std::numeric_limits<float>::infinity();
-            for (int i = 0; i < nk; ++i) if (!child_done[i])
+            for (int i = 0; i < nc; ++i) if (!child_done[i])
                 for (int s = 0; s < 8; ++s) if (!slot_used[s] && cost[i][s] > bc) { bc = cost[i][s]; bi = i; bs = s; }
             slot_of[bi] = bs; child_done[bi] = true; slot_used[bs] = true;
         }
         int in_slot[8]; for (int s = 0; s < 8; ++s) in_slot[s] = -1;
-        for (int i = 0; i < nk; ++i) in_slot[slot_of[i]] = kids[i];
+        for (int i = 0; i < nc; ++i) in_slot[slot_of[i]] = i;
 
         PmWideNode wn{};
         Box cb[8]; bool used[8];
         uint8_t imask = 0; uint32_t n_int = 0;
         for (int s = 0; s < 8; ++s) {
             used[s] = in_slot[s] >= 0;
-            if (used[s]) { cb[s] = bn[in_slot[s]].b; if (bn[in_slot[s]].left >= 0) { imask |= (uint8_t)(1u << s); ++n_int; } }
+            if (used[s]) { cb[s] = ch[in_slot[s]].b; if (ch[in_slot[s]].interior()) { imask |= (uint8_t)(1u << s); ++n_int; } }
         }
         quantise_node(wn, nb, cb, used);
         wn.imask = imask;
         wn.child_base = (uint32_t)acc.nodes.size();
         uint32_t prim_base_units = (uint32_t)(acc.prims.size() / 16);
-        wn.prim_base = prim_base_units | ((uint32_t)type << 30);
+        wn.prim_base = prim_base_units | ((uint32_t)node_type << 30);
         uint32_t rec_off = 0;
         // reserve interior children contiguously, in slot order
         acc.nodes.resize(acc.nodes.size() + n_int);
         uint32_t rank = 0;
         for (int s = 0; s < 8; ++s) {
             if (!used[s]) { wn.meta[s] = 0; continue; }
-            const BinNode& c = bn[in_slot[s]];
-            if (c.left >= 0) {
+            const Child& c = ch[in_slot[s]];
+            if (c.interior()) {
                 wn.meta[s] = 0;
-                queue.emplace_back(wn.child_base + rank, in_slot[s]);
+                queue.push_back(Work{wn.child_base + rank, c.bin, c.group});
                 ++rank;
             } else {
-                wn.meta[s] = (uint8_t)((c.count << 5) | rec_off);
-                for (uint32_t i = 0; i < c.count; ++i) emit_record(order[c.first + i]);
-                rec_off += c.count;
+                const BinNode& l = bn[c.bin];
+                wn.meta[s] = (uint8_t)((l.count << 5) | rec_off);
+                for (uint32_t i = 0; i < l.count; ++i) emit_record(order[l.first + i]);
+                rec_off += l.count;
             }
         }
-        acc.nodes[wi] = wn;
+        acc.nodes[w.wide] = wn;
     }
 
     void run(uint32_t root_wide, int root_bin) {
-        std::vector<std::pair<uint32_t, int>> queue;
-        queue.emplace_back(root_wide, root_bin);
+        std::vector<Work> queue;
+        queue.push_back(Work{root_wide, root_bin, {}});
         size_t head = 0;
         while (head < queue.size()) {
-            auto [wi, b] = queue[head++];
-            fill(wi, b, queue);
+            const Work w = queue[head++];
+            fill(w, queue);
         }
     }
 };
+
+// PBRT_MI355_UNIFIED_TREE=0: round 2's tree per primitive type under a join node (A/B and tests)
+static bool unified_tree() {
+    const char* e = std::getenv("PBRT_MI355_UNIFIED_TREE");
+    return !(e && std::atoi(e) == 0);
+}
 
 int build_accel(const HostScene& sc, int max_leaf, Accel& acc, std::string& err) {
     auto t0 = std::chrono::steady_clock::now();
@@ -293,6 +357,8 @@ int build_accel(const HostScene& sc, int max_leaf, Accel& acc, std::string& err)
     size_t n_total = sc.spheres.size() + sc.patches.size() + sc.tris.size();
     if (n_total == 0) { err = "no primitives"; return 1; }
 
+    const int n_types = (sc.spheres.empty() ? 0 : 1) + (sc.patches.empty() ? 0 : 1) + (sc.tris.empty() ? 0 : 1);
+    const bool unified = n_types > 1 && unified_tree();
     struct TypeTree { int type; std::vector<Box> boxes; std::vector<uint32_t> order, l2g; std::vector<BinNode> bn; int root; };
     std::vector<TypeTree> trees;
     auto add_type = [&](int type, size_t n, auto box_fn) {
@@ -305,6 +371,7 @@ int build_accel(const HostScene& sc, int max_leaf, Accel& acc, std::string& err)
         // pre-filter trip for all lanes, which costs more than the node it saves (measured, profiles/r01/leaf_sweep.log:
         // leaves <= 4 / <= 2 / 1 -> 2218 / 2233 / 2339 Mrays/s on C3, 214 / 221 / 252 Msamples/s on the C4-shaped scene).
         // max_prims_in_node stays the upper bound for spheres and patches, whose tests are not pre-filtered in the walk.
+        if (unified) return;            // (one tree over all types below: only the boxes are needed)
         BinBuilder bb(t.boxes, t.order, type == PM_PRIM_TRI ? 1 : max_leaf);
         t.bn.reserve(2 * n);
         t.root = bb.build(t.bn, 0, (uint32_t)n, 0);
@@ -314,13 +381,32 @@ int build_accel(const HostScene& sc, int max_leaf, Accel& acc, std::string& err)
     add_type(PM_PRIM_TRI, sc.tris.size(), [&](size_t i) { return sc.tris[i].bounds; });
 
     Box total = box_empty();
-    for (auto& t : trees) total = box_union(total, t.bn[t.root].b);
+    for (auto& t : trees) for (const Box& b : t.boxes) total = box_union(total, b);
     acc.bounds = total;
 
     if (trees.size() == 1) {
         acc.nodes.resize(1);
         Collapser c{trees[0].bn, trees[0].order, trees[0].type, acc, sc, trees[0].l2g};
         c.run(0, trees[0].root);
+    } else if (unified) {
+        // ONE tree over all primitives (round 3): binned SAH on the boxes alone, leaves of one type each (BinBuilder::leaf_ok),
+        // wide nodes whose leaves share a type (Collapser::fill).  Round 2 built a tree per type under a join node; every ray
+        // then walked every type's tree (a million triangles + 512 spheres: ~15 % more node steps; half triangles, half patches
+        // in the same space: twice the steps).
+        std::vector<Box> boxes; std::vector<uint32_t> order, l2g; std::vector<uint8_t> types;
+        for (auto& t : trees) {
+            for (size_t i = 0; i < t.boxes.size(); ++i) { boxes.push_back(t.boxes[i]); l2g.push_back((uint32_t)i); types.push_back((uint8_t)t.type); }
+        }
+        order.resize(boxes.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t)i;
+        BinBuilder bb(boxes, order, max_leaf);
+        bb.types = &types;
+        bb.max_leaf_of[PM_PRIM_SPHERE] = max_leaf; bb.max_leaf_of[PM_PRIM_PATCH] = max_leaf; bb.max_leaf_of[PM_PRIM_TRI] = 1;
+        std::vector<BinNode> bn; bn.reserve(2 * boxes.size());
+        const int root = bb.build(bn, 0, (uint32_t)boxes.size(), 0);
+        acc.nodes.resize(1);
+        Collapser c{bn, order, 0, acc, sc, l2g, &types};
+        c.run(0, root);
     } else {
         // join node: one interior child per primitive type
         acc.nodes.resize(1 + trees.size());
