@@ -291,7 +291,7 @@ void ora_wide_packet_model(const void* nodes_, const void* prims_, const OraRay*
         struct LaneS { V3 ro, rd; float inv[3]; bool ng[3]; float R, D, tcull; bool live; };
         const float widen = 1.0f + 2.0f * gamma_n(3);
         const float MARGIN = 2.384185791015625e-07f;
-        auto rcp = [](float d) { return std::fabs(d) < 1e-18f ? std::copysign(1e18f, d) : 1.0f / d; };
+        auto rcp = [](float d, float D) { return std::fabs(d) < 1e-18f * D ? std::copysign(1e18f / D, d) : 1.0f / d; };   // safe_rcp_dir
         std::vector<std::pair<uint32_t, uint64_t>> stack;
         for (uint64_t w = b; w < e; ++w) {
             LaneS L[64];
@@ -304,7 +304,8 @@ void ora_wide_packet_model(const void* nodes_, const void* prims_, const OraRay*
                 L[l].ro = V3(r.o[0], r.o[1], r.o[2]); L[l].rd = V3(r.d[0], r.d[1], r.d[2]);
                 const float d3[3] = {r.d[0], r.d[1], r.d[2]};
                 uint32_t oct = 0;
-                for (int k = 0; k < 3; ++k) { L[l].inv[k] = rcp(d3[k]); L[l].ng[k] = L[l].inv[k] < 0; oct |= L[l].ng[k] ? 1u << k : 0u; }
+                const float Dl = WideWalker::maxabs(L[l].rd);
+                for (int k = 0; k < 3; ++k) { L[l].inv[k] = rcp(d3[k], Dl); L[l].ng[k] = L[l].inv[k] < 0; oct |= L[l].ng[k] ? 1u << k : 0u; }
                 L[l].R = WideWalker::maxabs(L[l].ro); L[l].D = WideWalker::maxabs(L[l].rd); L[l].tcull = r.tmax; L[l].live = true;
                 live |= 1ull << l;
                 if (!have) { poct = oct; have = true; } else if (oct != poct) mixed = true;

@@ -288,7 +288,7 @@ struct WideWalker {
                 if (sphere_prefilter(ro, rd, R, D, f, f[12], f[18], f[19], tcs)) defer_prim(unit);
             }
             if (!any_hit) {
-                auto rcp = [](float d) { return std::fabs(d) < 1e-18f ? std::copysign(1e18f, d) : 1.0f / d; };
+                auto rcp = [D](float d) { return std::fabs(d) < 1e-18f * D ? std::copysign(1e18f / D, d) : 1.0f / d; };   // pm_device.hpp safe_rcp_dir
                 const V3 inv(rcp(rd.x), rcp(rd.y), rcp(rd.z));
                 for (uint32_t unit : ft.patches) {
                     if (slow) break;
@@ -347,11 +347,11 @@ struct WideWalker {
         const float widen = 1.0f + 2.0f * gamma_n(3);
         const float MARGIN = 2.384185791015625e-07f;
         const uint32_t CAND_MAX = 4;
-        auto rcp = [](float d) { return std::fabs(d) < 1e-18f ? std::copysign(1e18f, d) : 1.0f / d; };
+        const float R = maxabs(ro), D = maxabs(rd);
+        auto rcp = [D](float d) { return std::fabs(d) < 1e-18f * D ? std::copysign(1e18f / D, d) : 1.0f / d; };   // pm_device.hpp safe_rcp_dir
         const float inv[3] = {rcp(rd.x), rcp(rd.y), rcp(rd.z)};
         const bool ng[3] = {inv[0] < 0, inv[1] < 0, inv[2] < 0};
         const uint32_t oct = (ng[0] ? 1u : 0u) | (ng[1] ? 2u : 0u) | (ng[2] ? 4u : 0u);
-        const float R = maxabs(ro), D = maxabs(rd);
         const float o3[3] = {ro.x, ro.y, ro.z};
         struct Group { uint32_t base, imask, pm; };
         bool found = false;

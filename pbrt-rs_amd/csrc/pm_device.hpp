@@ -512,7 +512,10 @@ struct SlowWriter {
 #define PM_FLAT_UNROLL 4       /* triangle loop of the sweep: four table entries per scalar-load wait (1 / 2 / 4 / 8 measured: closest
                                   sweep of the C2 frame 16.87 / 16.43 / 16.25 / 16.33 ms; registers unchanged) */
 #endif
-PMD float safe_rcp_dir(float d) { return fabsf(d) < 1e-18f ? copysignf(1e18f, d) : 1.0f / d; }
+// (relative to D = the largest |component| of the direction, so that a ray and the same ray with its direction scaled by any
+// factor walk the same way: with round 2's absolute 1e-18 a direction of LENGTH ~1e-18 - legal, the reference finds its hits
+// at t ~ 1e18 - had every component replaced and missed everything; scripts/fuzz_trace.py found it)
+PMD float safe_rcp_dir(float d, float D) { return fabsf(d) < 1e-18f * D ? copysignf(1e18f / D, d) : 1.0f / d; }
 #define PM_NODE_MARGIN 2.384185791015625e-07f   /* 4 * 2^-24: rounding of the pre-scaled slab evaluation */
 #define PM_WALK_GUARD (1u << 22)                /* per-ray bound on node steps (a corrupt buffer cannot hang a wave) */
 
@@ -833,10 +836,10 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                         // 1/d for the slab test; a (near-)zero component gets a huge FINITE reciprocal so that the pre-scaled form
                         // q*(s/d) + (o - ro)/d stays a number (with +-inf it is inf - inf = NaN = "no constraint", and an
                         // axis-parallel ray would visit every box of its axis-aligned column)
-                        inv = mk3(safe_rcp_dir(ray.d.x), safe_rcp_dir(ray.d.y), safe_rcp_dir(ray.d.z));
+                        R = maxc3(abs3(ray.o)); D = maxc3(abs3(ray.d));
+                        inv = mk3(safe_rcp_dir(ray.d.x, D), safe_rcp_dir(ray.d.y, D), safe_rcp_dir(ray.d.z, D));
                         ngx = inv.x < 0.0f; ngy = inv.y < 0.0f; ngz = inv.z < 0.0f;
                         oct = (ngx ? 1u : 0u) | (ngy ? 2u : 0u) | (ngz ? 4u : 0u);
-                        R = maxc3(abs3(ray.o)); D = maxc3(abs3(ray.d));
                         exact_mode = false;
                         start_walk();
                         }
@@ -1187,7 +1190,7 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
         // 1e-4 of the coordinates and compares with a relative slack of 1e-4: it accepts a superset.)
         float t_rej = INFINITY;
         if (PATCH && !ANY) {        // (round 1 ran the reference arithmetic at once, for every ray and every patch: ~300 instructions each)
-            const f3 pinv = mk3(safe_rcp_dir(ray.d.x), safe_rcp_dir(ray.d.y), safe_rcp_dir(ray.d.z));
+            const f3 pinv = mk3(safe_rcp_dir(ray.d.x, D), safe_rcp_dir(ray.d.y, D), safe_rcp_dir(ray.d.z, D));
             for (uint32_t i = 0; i < fs.n_patch; ++i) {
                 const uint32_t unit = as_uniform(fs.units)[fs.n_sphere + i];
                 if (live && !slow) {
