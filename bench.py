@@ -450,6 +450,32 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup, work
         dt = float(t.item())
     ms_k /= steps
     launches /= steps
+    # Two lanes (pm_render alternates the passes of a frame between two streams): kernels of the two lanes share
+    # the chip, so the per-class times of the steps above overlap and say nothing about a kernel.  The roofline therefore comes
+    # from a second timed region of the same steps on ONE lane (PBRT_MI355_LANES=1, read by the library at call time), where
+    # every kernel has the chip to itself as under rocprofv3; `value` stays the two-lane rate.
+    lanes = {"used": 1}
+    if "PBRT_MI355_LANES" not in os.environ:
+        os.environ["PBRT_MI355_LANES"] = "1"
+        try:
+            step()
+            barrier()
+            ms_1, launches_1 = np.zeros(5), np.zeros(5)
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                st_1 = step()
+                ms_1 += np.asarray(st_1["ms_by_kernel"])
+                launches_1 += np.asarray(st_1["launches_by_kernel"])
+            barrier()
+            dt_1 = time.perf_counter() - t1
+        finally:
+            del os.environ["PBRT_MI355_LANES"]
+        if st_1["passes"] != st["passes"]:
+            lanes = {"used": 2, "ms_per_step_one_lane": dt_1 / steps * 1e3, "speedup_over_one_lane": dt_1 / dt,
+                     "sum_of_class_ms_two_lanes": float(ms_k.sum()),
+                     "roofline_region": f"{steps} further timed steps with PBRT_MI355_LANES=1 (kernels alone on the chip); "
+                                        "`value` and `ms_per_step` are the two-lane steps"}
+            ms_k, launches = ms_1 / steps, launches_1 / steps
     samples = st["samples"]
     total_samples = samples * world if not rows else rw * rh * spp_total
     if world > 1 and not rows:
@@ -511,11 +537,12 @@ def run_path(args, pm, torch, dist, rank, local_rank, world, steps, warmup, work
                                                 "occupancy": [float(x) / max(1.0, float(q_closest[0])) for x in q_closest]},
                    "generator": "numpy PCG64 (default_rng); see scenes.py"},
         "roofline": roof,
+        "lanes": lanes,
     }
     return out, sd, integ, (spp, max_depth, integrator)
 
 
-def sub(out, keys=("value", "unit", "ms_per_step", "roofline", "cpu_baseline")):
+def sub(out, keys=("value", "unit", "ms_per_step", "roofline", "cpu_baseline", "lanes")):
     d = {k: out[k] for k in keys if k in out}
     d["workload"] = out["config"]["workload"]
     d["config"] = {k: v for k, v in out["config"].items() if k != "workload"}
@@ -555,6 +582,8 @@ def _leg_short(leg):
     o = {"value": float(f"{leg['value']:.6g}"), "unit": leg["unit"], "workload": leg.get("workload", "")[:110]}
     if "ms_per_step" in leg:
         o["ms_per_step"] = float(f"{leg['ms_per_step']:.5g}")
+    if (leg.get("lanes") or {}).get("used") == 2:
+        o["one_lane_ms"] = float(f"{leg['lanes']['ms_per_step_one_lane']:.5g}")
     r = _roof_short(leg.get("roofline"))
     if r:
         o["roofline"] = _pick(r, ("bound", "achieved", "frac", "traffic", "kernel", "kernel_ms", "launches_per_step", "bytes_per_launch"))
@@ -582,6 +611,10 @@ def headline(full, full_path):
             h["config"][k] = cfg[k]
     h["roofline"] = _roof_short(full.get("roofline"))
     h["cpu_baseline"] = _cpu_short(full.get("cpu_baseline"))
+    ln = full.get("lanes") or {}
+    if ln.get("used") == 2:     # value / ms_per_step: two lanes; roofline: the same steps on one lane (kernels alone on the chip)
+        h["lanes"] = {"used": 2, "one_lane_ms_per_step": float(f"{ln['ms_per_step_one_lane']:.5g}"),
+                      "roofline_from": "timed one-lane steps"}
     for key in ("c2_point_light", "closest_hit", "c4_path", "c4_strong", "c5_path", "patch_mesh"):
         if key in full:
             h[key] = _leg_short(full[key])

@@ -119,17 +119,18 @@ static inline bool is_device_ptr(const void* p) {
 }
 static inline int ensure(pm_ctx* c, void** buf, size_t* cap, size_t need);
 // room for one second-pass entry per work item of a traversal launch (scenes with spheres, and every flat-swept scene)
-static inline int ensure_defer(pm_ctx* c, size_t items) {
+static inline int ensure_defer_buf(pm_ctx* c, size_t items, uint4** d_defer, uint32_t** d_slow, size_t* cap) {
     // + what the waves of the largest traversal grid can leave unused of their reservations (pm_device.hpp DeferWriter)
     items += (size_t)c->n_cu * PM_FLAT_BLOCKS_PER_CU * (TRACE_BLOCK / 64) * 256;
-    if ((c->scene.spheres.empty() && !c->flat.tris) || c->defer_cap >= items) return PM_OK;
-    if (c->d_defer) { HIPCHK(c, hipFree(c->d_defer)); c->d_defer = nullptr; c->defer_cap = 0; }
-    if (c->d_slow) { HIPCHK(c, hipFree(c->d_slow)); c->d_slow = nullptr; }
-    HIPCHK(c, hipMalloc((void**)&c->d_defer, items * sizeof(uint4)));
-    HIPCHK(c, hipMalloc((void**)&c->d_slow, items * sizeof(uint32_t)));
-    c->defer_cap = items;
+    if ((c->scene.spheres.empty() && !c->flat.tris) || *cap >= items) return PM_OK;
+    if (*d_defer) { HIPCHK(c, hipFree(*d_defer)); *d_defer = nullptr; *cap = 0; }
+    if (*d_slow) { HIPCHK(c, hipFree(*d_slow)); *d_slow = nullptr; }
+    HIPCHK(c, hipMalloc((void**)d_defer, items * sizeof(uint4)));
+    HIPCHK(c, hipMalloc((void**)d_slow, items * sizeof(uint32_t)));
+    *cap = items;
     return PM_OK;
 }
+static inline int ensure_defer(pm_ctx* c, size_t items) { return ensure_defer_buf(c, items, &c->d_defer, &c->d_slow, &c->defer_cap); }
 static inline int ensure(pm_ctx* c, void** buf, size_t* cap, size_t need) {
     if (*cap >= need) return PM_OK;
     if (*buf) HIPCHK(c, hipFree(*buf));

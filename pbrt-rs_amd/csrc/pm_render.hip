@@ -1081,12 +1081,19 @@ struct RenderState {
     int n_inf = 0;
     DFilter dfilter{}; int sensor_off = 0;
     double* d_film = nullptr; size_t film_pixels = 0;
-    // path arrays
-    PathArrays pa{}; size_t pa_cap = 0; int pa_depth = 0;
-    std::vector<void*> pa_allocs;
+    // path arrays: one set per LANE.  A frame of several passes is rendered on two lanes - two streams, each with its own path
+    // state, work counters and deferred lists - whose passes alternate (render_impl): the sweep / walk kernels of one lane are
+    // bound by instruction issue, the shade kernel of the other waits on memory, and together they fill the chip better than
+    // either alone.  Lane 0 uses the context's stream and lists, lane 1 what is kept here.
+    struct PathBuf { PathArrays pa{}; size_t cap = 0; int depth = 0; std::vector<void*> allocs; };
+    PathBuf pb[2];
+    hipStream_t stream1 = nullptr;
+    uint32_t* d_work1 = nullptr; uint4* d_defer1 = nullptr; uint32_t* d_slow1 = nullptr; size_t defer_cap1 = 0;
+    hipEvent_t ev_go = nullptr, ev_acc[2] = {nullptr, nullptr}, ev_join = nullptr;
+    uint32_t* h_counts[2] = {nullptr, nullptr}; size_t h_counts_words = 0;     // pinned: queue lengths of a lane's pass
     PmRenderStats stats{};
     std::vector<uint64_t> q_closest, q_shadow;      // queue entries per bounce of the last render (all passes)
-    std::vector<hipEvent_t> ev_pool;      // per-launch timing: one event before every kernel of a pass + one after
+    std::vector<hipEvent_t> ev_pool[2];   // per lane, per-launch timing: one event before every kernel of a pass + one after
     // PBRT_MI355_REORDER: keys / values in and out of the radix sort, its scratch
     uint32_t* d_sort[4] = {nullptr, nullptr, nullptr, nullptr}; void* d_sort_tmp = nullptr; size_t sort_cap = 0, sort_tmp_bytes = 0;
 };
@@ -1094,8 +1101,14 @@ struct RenderState {
 void pm_render_state_destroy(pm_ctx* c) {
     RenderState* r = c->render;
     if (!r) return;
-    for (void* p : r->pa_allocs) (void)hipFree(p);
-    for (hipEvent_t e : r->ev_pool) (void)hipEventDestroy(e);
+    for (auto& b : r->pb) for (void* p : b.allocs) (void)hipFree(p);
+    for (auto& pool : r->ev_pool) for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {r->ev_go, r->ev_acc[0], r->ev_acc[1], r->ev_join}) if (e) (void)hipEventDestroy(e);
+    for (uint32_t* h : r->h_counts) if (h) (void)hipHostFree(h);
+    if (r->d_work1) (void)hipFree(r->d_work1);
+    if (r->d_defer1) (void)hipFree(r->d_defer1);
+    if (r->d_slow1) (void)hipFree(r->d_slow1);
+    if (r->stream1) (void)hipStreamDestroy(r->stream1);
     void* ptrs[] = {r->d_pool, r->d_mats, r->d_lights, r->d_inf, r->d_prim_ref, r->d_patches, r->d_spheres, r->d_m9, r->d_film};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (uint32_t* p : r->d_sort) if (p) (void)hipFree(p);
@@ -1408,12 +1421,12 @@ static int upload_scene(pm_ctx* c, RenderState* r) {
     return PM_OK;
 }
 
-static int ensure_paths(pm_ctx* c, RenderState* r, size_t npaths, int max_depth, bool random_walk) {
-    if (r->pa_cap >= npaths && r->pa_depth >= max_depth && (!random_walk || r->pa.rw_f)) return PM_OK;
-    for (void* p : r->pa_allocs) HIPCHK(c, hipFree(p));
-    r->pa_allocs.clear(); r->pa_cap = 0;
-    auto al = [&](void** p, size_t bytes) -> int { HIPCHK(c, hipMalloc(p, bytes)); r->pa_allocs.push_back(*p); return PM_OK; };
-    PathArrays& pa = r->pa;
+static int ensure_paths(pm_ctx* c, RenderState::PathBuf* b, size_t npaths, int max_depth, bool random_walk) {
+    if (b->cap >= npaths && b->depth >= max_depth && (!random_walk || b->pa.rw_f)) return PM_OK;
+    for (void* p : b->allocs) HIPCHK(c, hipFree(p));
+    b->allocs.clear(); b->cap = 0;
+    auto al = [&](void** p, size_t bytes) -> int { HIPCHK(c, hipMalloc(p, bytes)); b->allocs.push_back(*p); return PM_OK; };
+    PathArrays& pa = b->pa;
     float4** f4[] = {&pa.ro[0], &pa.ro[1], &pa.rd[0], &pa.rd[1], &pa.beta[0], &pa.beta[1],
                      &pa.hit, &pa.sh_o, &pa.sh_d, &pa.sh_L, &pa.L, &pa.lambda_s, &pa.pdf};
     int rc;
@@ -1424,7 +1437,7 @@ static int ensure_paths(pm_ctx* c, RenderState* r, size_t npaths, int max_depth,
     if ((rc = al((void**)&pa.counts, 2 * (size_t)(max_depth + 2) * 4 * PM_CNT_STRIDE))) return rc;
     pa.rw_f = nullptr; pa.cap = (uint32_t)npaths;
     if (random_walk && (rc = al((void**)&pa.rw_f, (size_t)std::max(1, max_depth) * npaths * sizeof(float4)))) return rc;
-    r->pa_cap = npaths; r->pa_depth = max_depth;
+    b->cap = npaths; b->depth = max_depth;
     return PM_OK;
 }
 
@@ -1462,19 +1475,34 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     {   // ... but never more than half of the memory that is free on the device now (another process may share it)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t held = r->pa_cap * (size_t)PM_PATH_BYTES;         // what ensure_paths would free first
+            const size_t held = (r->pb[0].cap + r->pb[1].cap) * (size_t)PM_PATH_BYTES;         // what ensure_paths would free first
             const size_t per_path = PM_PATH_BYTES + 16 + 4 + (p->integrator == PM_INTEGRATOR_RANDOM_WALK ? (size_t)std::max(1, p->max_depth) * 16 : 0);
             target = std::min(target, std::max<size_t>((size_t)1 << 16, (free_b + held) / 2 / per_path));
         }
     }
+    // Lanes (round 3).  PBRT_MI355_LANES: 1 = one stream as before; 2 = two lanes whenever the call has at least two sample
+    // indices; unset = two lanes for calls of at least 2^22 paths (below that the launches are too short to gain from it).  The
+    // path-state memory is the same either way: with two lanes a pass is half as large.  scripts/overlap_probe.py was the
+    // feasibility test (two contexts on two host threads: +11 % on C2); profiles/r03/ab_lanes.log is the measurement.
+    int lanes = 0;
+    if (const char* e = std::getenv("PBRT_MI355_LANES")) lanes = std::atoi(e);
+    if (lanes != 1 && lanes != 2) lanes = npix_pad * (size_t)(s1 - s0) >= ((size_t)1 << 22) ? 2 : 1;
+    if (debug_one || (s1 - s0) < 2 || std::getenv("PBRT_MI355_VERIFY") || std::getenv("PBRT_MI355_REORDER")) lanes = 1;
     int s_per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)(s1 - s0), target / npix_pad));
+    if (lanes == 2) s_per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)(s1 - s0 + 1) / 2, (target / 2) / npix_pad));
     const size_t max_paths = npix_pad * (size_t)s_per_pass;
     if (max_paths > 0x7FFFFFFFull) return fail(c, PM_ERR_INVALID, "pm_render: window too large for one pass");
     const bool random_walk = p->integrator == PM_INTEGRATOR_RANDOM_WALK;
     if (random_walk && (r->have_textures || r->have_area_lights))
         return fail(c, PM_ERR_UNSUPPORTED, "pm_render: the RandomWalk kernel supports neither textures nor area lights (extensions of SimplePath / VolPath)");
-    if ((rcode = ensure_paths(c, r, max_paths, p->max_depth, random_walk))) return rcode;
+    for (int l = 0; l < lanes; ++l) if ((rcode = ensure_paths(c, &r->pb[l], max_paths, p->max_depth, random_walk))) return rcode;
     if ((rcode = ensure_defer(c, max_paths))) return rcode;
+    if (lanes == 2) {
+        if (!r->stream1) HIPCHK(c, hipStreamCreateWithFlags(&r->stream1, hipStreamNonBlocking));
+        if (!r->d_work1) HIPCHK(c, hipMalloc((void**)&r->d_work1, 3 * PM_WORK_SLOTS * sizeof(uint32_t)));
+        if ((rcode = ensure_defer_buf(c, max_paths, &r->d_defer1, &r->d_slow1, &r->defer_cap1))) return rcode;
+    }
+    for (hipEvent_t* e : {&r->ev_go, &r->ev_acc[0], &r->ev_acc[1], &r->ev_join}) if (!*e) HIPCHK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
     const bool has_spheres = !c->scene.spheres.empty();
     const int kind = pm_walk_kind(c);      // tree-walk kernel variant
     // PBRT_MI355_REORDER=<bits per axis, 1..9> (experiment, off by default - measured in profiles/r03/ab_reorder.log): before the
@@ -1522,13 +1550,15 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     rc.film_x0 = pb[0]; rc.film_y0 = pb[1]; rc.film_w = pb[2] - pb[0];
     SceneArrays sa{c->d_nodes, c->d_prims, r->direct_records ? nullptr : r->d_prim_ref, r->d_patches, r->d_spheres, r->d_mats, r->d_lights,
                    r->d_inf, r->d_pool, r->have_area_lights ? 1 : 0};
-    PathArrays& pa = r->pa;
     const int nb = p->max_depth + 2;
-    std::vector<uint32_t> hcounts(2 * (size_t)nb * PM_CNT_STRIDE);
+    const size_t cnt_words = 2 * (size_t)nb * PM_CNT_STRIDE;
+    if (r->h_counts_words < cnt_words) {
+        for (uint32_t*& h : r->h_counts) { if (h) (void)hipHostFree(h); h = nullptr; HIPCHK(c, hipHostMalloc((void**)&h, cnt_words * sizeof(uint32_t))); }
+        r->h_counts_words = cnt_words;
+    }
     const size_t max_launch = 3 * (size_t)(p->max_depth + 1) + 3;
-    while (r->ev_pool.size() < max_launch + 1) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); r->ev_pool.push_back(e); }
-    std::vector<int> ev_class; ev_class.reserve(max_launch);
-    auto mark = [&](int cls) { (void)hipEventRecord(r->ev_pool[ev_class.size()], c->stream); ev_class.push_back(cls); };
+    for (int l = 0; l < lanes; ++l)
+        while (r->ev_pool[l].size() < max_launch + 1) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); r->ev_pool[l].push_back(e); }
     unsigned long long cnt_before[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(c, hipMemcpy(cnt_before, c->d_counters, sizeof(cnt_before), hipMemcpyDeviceToHost));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -1542,41 +1572,98 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
         HIPCHK(c, hipMalloc((void**)&verify_recs, 64 * sizeof(VerifyRec)));
         HIPCHK(c, pm_memset_sync(c, verify_bad, sizeof(uint32_t)));
     }
-    for (int sb = s0; sb < s1; sb += s_per_pass) {
+    // Two lanes: pass k runs on lane k & 1.  What orders them: (i) lane 1 starts behind whatever the caller's last call left on
+    // the context's stream (ev_go, recorded there - after the first `stagger` launches of pass 0, so that the two lanes are in
+    // different phases of a bounce from the start: a sweep beside a shade kernel, not two of a kind); (ii) the film is added
+    // to in sample-index order: the accumulate launch of pass k waits for that of pass k - 1 (ev_acc); (iii) a lane's buffers
+    // are reused by its next pass, which the host issues once it has collected the counts of the previous one.
+    int stagger = 2, grid_div = 1;
+    if (const char* e = std::getenv("PBRT_MI355_STAGGER")) { int v = std::atoi(e); if (v >= 0 && v <= 64) stagger = v; }
+    if (const char* e = std::getenv("PBRT_MI355_LANE_GRID_DIV")) { int v = std::atoi(e); if (v >= 1 && v <= 4) grid_div = v; }
+    if (lanes == 1) grid_div = 1;
+    struct LaneRun { bool busy = false; std::vector<int> ev_class; int s_count = 0; };
+    LaneRun run[2];
+    hipStream_t streams[2] = {c->stream, r->stream1};
+    uint32_t* works[2] = {c->d_work, r->d_work1};
+    uint4* defers[2] = {c->d_defer, r->d_defer1};
+    uint32_t* slows[2] = {c->d_slow, r->d_slow1};
+    const size_t defer_caps[2] = {c->defer_cap, r->defer_cap1};
+    // collect what a lane's finished pass left: per-class times, queue lengths
+    auto harvest = [&](int l) -> int {
+        LaneRun& lr = run[l];
+        if (!lr.busy) return PM_OK;
+        HIPCHK(c, hipStreamSynchronize(streams[l]));
+        for (size_t e = 0; e < lr.ev_class.size(); ++e) {
+            float ems = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ems, r->ev_pool[l][e], r->ev_pool[l][e + 1]));
+            r->stats.ms_by_kernel[lr.ev_class[e]] += ems;
+            r->stats.launches_by_kernel[lr.ev_class[e]] += 1;
+        }
+        const uint32_t* hcounts = r->h_counts[l];
+        r->stats.passes++;
+        r->stats.samples += (uint64_t)W * H * lr.s_count;
+        // closest rays: every live path in the queue of bounce b (padded slots are not live)
+        const uint64_t pad = (uint64_t)(npix_pad - (size_t)W * H) * lr.s_count;
+        for (int b = 0; b <= p->max_depth; ++b) {
+            r->q_closest[b] += hcounts[(size_t)b * PM_CNT_STRIDE] - (b == 0 ? pad : 0);
+            r->q_shadow[b] += hcounts[(size_t)(nb + b) * PM_CNT_STRIDE];
+        }
+        for (int b = 0; b <= p->max_depth; ++b) r->stats.closest_rays += hcounts[(size_t)b * PM_CNT_STRIDE] - (b == 0 ? pad : 0);
+        for (int b = 0; b < nb; ++b) r->stats.shadow_rays += hcounts[(size_t)(nb + b) * PM_CNT_STRIDE];
+        lr.busy = false;
+        return PM_OK;
+    };
+    int pass_index = 0;
+    for (int sb = s0; sb < s1; sb += s_per_pass, ++pass_index) {
+        const int l = lanes == 2 ? (pass_index & 1) : 0;
+        if ((rcode = harvest(l))) return rcode;
+        LaneRun& lr = run[l];
+        std::vector<int>& ev_class = lr.ev_class;
         ev_class.clear();
+        hipStream_t st = streams[l];
+        PathArrays& pa = r->pb[l].pa;
+        uint32_t* const d_work = works[l]; uint4* const d_defer = defers[l]; uint32_t* const d_slow = slows[l];
+        const uint32_t defer_cap = (uint32_t)defer_caps[l];
+        bool go_pending = lanes == 2 && pass_index == 0;
+        auto mark = [&](int cls) {
+            if (go_pending && (int)ev_class.size() == stagger) { (void)hipEventRecord(r->ev_go, st); go_pending = false; }
+            (void)hipEventRecord(r->ev_pool[l][ev_class.size()], st); ev_class.push_back(cls);
+        };
+        if (lanes == 2 && pass_index == 1) HIPCHK(c, hipStreamWaitEvent(st, r->ev_go, 0));
         rc.s_base = sb; rc.s_count = std::min(s_per_pass, s1 - sb);
+        lr.s_count = rc.s_count;
         const uint32_t npaths = (uint32_t)(npix_pad * (size_t)rc.s_count);
-        HIPCHK(c, hipMemsetAsync(pa.counts, 0, 2 * (size_t)nb * 4 * PM_CNT_STRIDE, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_work, 0, 3 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(pa.counts, 0, 2 * (size_t)nb * 4 * PM_CNT_STRIDE, st));
+        HIPCHK(c, hipMemsetAsync(d_work, 0, 3 * PM_WORK_SLOTS * sizeof(uint32_t), st));
         int wslot = 0;      // one work counter per traversal launch (re-zeroed when the slots run out)
         const dim3 gr((npaths + RB - 1) / RB);
-        const dim3 gt(std::min<uint32_t>((npaths + TB - 1) / TB, (uint32_t)c->n_cu * PM_BLOCKS_PER_CU));
-        const dim3 gf(std::min<uint32_t>((npaths + TB - 1) / TB, (uint32_t)c->n_cu * PM_FLAT_BLOCKS_PER_CU));
+        const dim3 gt(std::min<uint32_t>((npaths + TB - 1) / TB, (uint32_t)c->n_cu * PM_BLOCKS_PER_CU / grid_div));
+        const dim3 gf(std::min<uint32_t>((npaths + TB - 1) / TB, (uint32_t)c->n_cu * PM_FLAT_BLOCKS_PER_CU / grid_div));
         const bool flat = c->flat.tris != nullptr, fpatch = c->flat.n_patch > 0;
         mark(0);
-        hipLaunchKernelGGL(raygen_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, npaths);
+        hipLaunchKernelGGL(raygen_kernel, gr, dim3(RB), 0, st, rc, sa, pa, npaths);
         uint32_t gen = 0;       // generation of the path-state arrays that holds the current queue
         for (int b = 0; b <= p->max_depth; ++b) {
             uint32_t* cnt_in = pa.counts + (size_t)b * PM_CNT_STRIDE; uint32_t* cnt_out = pa.counts + (size_t)(b + 1) * PM_CNT_STRIDE;
             uint32_t* cnt_sh = pa.counts + (size_t)(nb + b) * PM_CNT_STRIDE;
             if (wslot + 2 > PM_WORK_SLOTS) {   // stream-ordered: every earlier traversal kernel has finished with its counter
-                HIPCHK(c, hipMemsetAsync(c->d_work, 0, 3 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream));
+                HIPCHK(c, hipMemsetAsync(d_work, 0, 3 * PM_WORK_SLOTS * sizeof(uint32_t), st));
                 wslot = 0;
             }
             mark(1);
             const uint32_t* perm = nullptr;
             if (reorder_bits && b >= 1) {
                 uint32_t n_q = 0;
-                HIPCHK(c, hipMemcpyAsync(&n_q, cnt_in, sizeof(n_q), hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(c, hipStreamSynchronize(c->stream));
+                HIPCHK(c, hipMemcpyAsync(&n_q, cnt_in, sizeof(n_q), hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipStreamSynchronize(st));
                 if (n_q >= 4096u) {
                     const pm::Box& bx = c->accel.bounds;
                     const float q = (float)(1u << reorder_bits);
                     auto sc1 = [&](int k) { const float e = bx.hi[k] - bx.lo[k]; return e > 0.0f ? q / e : 0.0f; };
-                    hipLaunchKernelGGL(reorder_key_kernel, dim3((n_q + RB - 1) / RB), dim3(RB), 0, c->stream, pa, gen, n_q, mk3(bx.lo[0], bx.lo[1], bx.lo[2]),
+                    hipLaunchKernelGGL(reorder_key_kernel, dim3((n_q + RB - 1) / RB), dim3(RB), 0, st, pa, gen, n_q, mk3(bx.lo[0], bx.lo[1], bx.lo[2]),
                                        mk3(sc1(0), sc1(1), sc1(2)), reorder_bits, reorder_oct_high, r->d_sort[0], r->d_sort[2]);
                     size_t tb = r->sort_tmp_bytes;
-                    if (pm_sort_pairs_u32(c->stream, r->d_sort_tmp, &tb, r->d_sort[0], r->d_sort[1], r->d_sort[2], r->d_sort[3], n_q, 3 * reorder_bits + 3))
+                    if (pm_sort_pairs_u32(st, r->d_sort_tmp, &tb, r->d_sort[0], r->d_sort[1], r->d_sort[2], r->d_sort[3], n_q, 3 * reorder_bits + 3))
                         return fail(c, PM_ERR_HIP, "pm_render: radix sort failed");
                     perm = r->d_sort[3];
                 }
@@ -1584,75 +1671,69 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
             if (flat) {
                 auto kernel = c->counting ? (fpatch ? closest_flat_kernel<true, true> : closest_flat_kernel<true, false>)
                                           : (fpatch ? closest_flat_kernel<false, true> : closest_flat_kernel<false, false>);
-                hipLaunchKernelGGL(kernel, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, gen, cnt_in, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, c->d_slow, c->d_counters);
+                hipLaunchKernelGGL(kernel, gf, dim3(TB), 0, st, c->flat, sa, pa, gen, cnt_in, d_defer, defer_cap, d_work + PM_WORK_SLOTS + wslot, d_slow, c->d_counters);
             } else {
                 auto kernel = c->counting ? (kind == PM_WALK_MIXED ? closest_kernel<true, PM_WALK_MIXED> : kind == PM_WALK_PATCH ? closest_kernel<true, PM_WALK_PATCH> : closest_kernel<true, PM_WALK_TRI>)
                                           : (kind == PM_WALK_MIXED ? closest_kernel<false, PM_WALK_MIXED> : kind == PM_WALK_PATCH ? closest_kernel<false, PM_WALK_PATCH> : closest_kernel<false, PM_WALK_TRI>);
-                hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, gen, cnt_in, c->d_work + wslot, c->refill, c->d_defer, (uint32_t)c->defer_cap, c->d_counters, perm);
+                hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, st, sa, pa, gen, cnt_in, d_work + wslot, c->refill, d_defer, defer_cap, c->d_counters, perm);
             }
             if (has_spheres || flat) {     // second pass: dense exact tests of what was deferred (timed with the closest-hit class)
-                if (c->counting) hipLaunchKernelGGL(closest_fix_kernel<true>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, gen, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
-                else hipLaunchKernelGGL(closest_fix_kernel<false>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, gen, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
+                if (c->counting) hipLaunchKernelGGL(closest_fix_kernel<true>, gt, dim3(TB), 0, st, c->flat, sa, pa, gen, d_defer, defer_cap, d_work + PM_WORK_SLOTS + wslot, flat ? d_slow : nullptr, c->d_counters);
+                else hipLaunchKernelGGL(closest_fix_kernel<false>, gt, dim3(TB), 0, st, c->flat, sa, pa, gen, d_defer, defer_cap, d_work + PM_WORK_SLOTS + wslot, flat ? d_slow : nullptr, c->d_counters);
             }
             ++wslot;
             if (verify && !c->counting && !flat && !has_spheres) {
                 // the same queue through the counting walk (the hits it leaves in pa.hit are the ones the pass goes on with)
-                HIPCHK(c, hipMemcpyAsync(verify_hits, pa.hit, (size_t)npaths * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
-                if (wslot + 2 > PM_WORK_SLOTS) { HIPCHK(c, hipMemsetAsync(c->d_work, 0, 3 * PM_WORK_SLOTS * sizeof(uint32_t), c->stream)); wslot = 0; }
+                HIPCHK(c, hipMemcpyAsync(verify_hits, pa.hit, (size_t)npaths * sizeof(float4), hipMemcpyDeviceToDevice, st));
+                if (wslot + 2 > PM_WORK_SLOTS) { HIPCHK(c, hipMemsetAsync(d_work, 0, 3 * PM_WORK_SLOTS * sizeof(uint32_t), st)); wslot = 0; }
                 auto kernel = kind == PM_WALK_MIXED ? closest_kernel<true, PM_WALK_MIXED> : kind == PM_WALK_PATCH ? closest_kernel<true, PM_WALK_PATCH> : closest_kernel<true, PM_WALK_TRI>;
-                hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, gen, cnt_in, c->d_work + wslot, c->refill, c->d_defer, (uint32_t)c->defer_cap, c->d_counters, (const uint32_t*)nullptr);
+                hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, st, sa, pa, gen, cnt_in, d_work + wslot, c->refill, d_defer, defer_cap, c->d_counters, (const uint32_t*)nullptr);
                 ++wslot;
-                hipLaunchKernelGGL(verify_hits_kernel, gr, dim3(RB), 0, c->stream, pa, gen, cnt_in, verify_hits, (uint32_t)b, verify_bad, verify_recs, 64u);
+                hipLaunchKernelGGL(verify_hits_kernel, gr, dim3(RB), 0, st, pa, gen, cnt_in, verify_hits, (uint32_t)b, verify_bad, verify_recs, 64u);
             }
             mark(2);
-            if (random_walk) hipLaunchKernelGGL(shade_rw_kernel, gr, dim3(RB), 0, c->stream, rc, sa, pa, gen, cnt_in, cnt_out);
-            else if (r->have_sphere_lights) hipLaunchKernelGGL((shade_kernel<true, true>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen | (b == 0 ? 2u : 0u), cnt_in, cnt_out, cnt_sh);
-            else if (shade_ext || force_ext) hipLaunchKernelGGL((shade_kernel<true, false>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen | (b == 0 ? 2u : 0u), cnt_in, cnt_out, cnt_sh);
-            else if (shade_area) hipLaunchKernelGGL((shade_kernel<false, true>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen | (b == 0 ? 2u : 0u), cnt_in, cnt_out, cnt_sh);
-            else hipLaunchKernelGGL((shade_kernel<false, false>), gr, dim3(RB), 0, c->stream, rc, sa, pa, gen | (b == 0 ? 2u : 0u), cnt_in, cnt_out, cnt_sh);
+            if (random_walk) hipLaunchKernelGGL(shade_rw_kernel, gr, dim3(RB), 0, st, rc, sa, pa, gen, cnt_in, cnt_out);
+            else if (r->have_sphere_lights) hipLaunchKernelGGL((shade_kernel<true, true>), gr, dim3(RB), 0, st, rc, sa, pa, gen | (b == 0 ? 2u : 0u), cnt_in, cnt_out, cnt_sh);
+            else if (shade_ext || force_ext) hipLaunchKernelGGL((shade_kernel<true, false>), gr, dim3(RB), 0, st, rc, sa, pa, gen | (b == 0 ? 2u : 0u), cnt_in, cnt_out, cnt_sh);
+            else if (shade_area) hipLaunchKernelGGL((shade_kernel<false, true>), gr, dim3(RB), 0, st, rc, sa, pa, gen | (b == 0 ? 2u : 0u), cnt_in, cnt_out, cnt_sh);
+            else hipLaunchKernelGGL((shade_kernel<false, false>), gr, dim3(RB), 0, st, rc, sa, pa, gen | (b == 0 ? 2u : 0u), cnt_in, cnt_out, cnt_sh);
             if (!random_walk && p->sample_lights && b < p->max_depth) {
                 mark(3);
                 if (flat) {
                     auto kernel = c->counting ? (fpatch ? shadow_flat_kernel<true, true> : shadow_flat_kernel<true, false>)
                                               : (fpatch ? shadow_flat_kernel<false, true> : shadow_flat_kernel<false, false>);
-                    hipLaunchKernelGGL(kernel, gf, dim3(TB), 0, c->stream, c->flat, sa, pa, cnt_sh, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, c->d_slow, c->d_counters);
+                    hipLaunchKernelGGL(kernel, gf, dim3(TB), 0, st, c->flat, sa, pa, cnt_sh, d_defer, defer_cap, d_work + PM_WORK_SLOTS + wslot, d_slow, c->d_counters);
                 } else {
                     auto kernel = c->counting ? (kind == PM_WALK_MIXED ? shadow_kernel<true, PM_WALK_MIXED> : kind == PM_WALK_PATCH ? shadow_kernel<true, PM_WALK_PATCH> : shadow_kernel<true, PM_WALK_TRI>)
                                               : (kind == PM_WALK_MIXED ? shadow_kernel<false, PM_WALK_MIXED> : kind == PM_WALK_PATCH ? shadow_kernel<false, PM_WALK_PATCH> : shadow_kernel<false, PM_WALK_TRI>);
-                    hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, c->stream, sa, pa, cnt_sh, c->d_work + wslot, c->refill, c->d_defer, (uint32_t)c->defer_cap, c->d_counters);
+                    hipLaunchKernelGGL(kernel, gt, dim3(TB), 0, st, sa, pa, cnt_sh, d_work + wslot, c->refill, d_defer, defer_cap, c->d_counters);
                 }
                 if (has_spheres || flat) {
-                    if (c->counting) hipLaunchKernelGGL(shadow_fix_kernel<true>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
-                    else hipLaunchKernelGGL(shadow_fix_kernel<false>, gt, dim3(TB), 0, c->stream, c->flat, sa, pa, c->d_defer, (uint32_t)c->defer_cap, c->d_work + PM_WORK_SLOTS + wslot, flat ? c->d_slow : nullptr, c->d_counters);
+                    if (c->counting) hipLaunchKernelGGL(shadow_fix_kernel<true>, gt, dim3(TB), 0, st, c->flat, sa, pa, d_defer, defer_cap, d_work + PM_WORK_SLOTS + wslot, flat ? d_slow : nullptr, c->d_counters);
+                    else hipLaunchKernelGGL(shadow_fix_kernel<false>, gt, dim3(TB), 0, st, c->flat, sa, pa, d_defer, defer_cap, d_work + PM_WORK_SLOTS + wslot, flat ? d_slow : nullptr, c->d_counters);
                 }
                 ++wslot;
             }
             gen ^= 1u;
             r->stats.kernels_launched += 3;
         }
-        if (!debug_one) mark(4);
-        if (!debug_one)
-            hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((npix_pad + RB - 1) / RB)), dim3(RB), 0, c->stream, rc, sa, pa, r->d_film);
+        if (go_pending) { HIPCHK(c, hipEventRecord(r->ev_go, st)); go_pending = false; }      // (a pass of fewer launches than `stagger`)
+        if (!debug_one) {
+            mark(4);        // (with two lanes the accumulate class also holds the wait for the other lane's previous pass)
+            if (lanes == 2 && pass_index > 0) HIPCHK(c, hipStreamWaitEvent(st, r->ev_acc[l ^ 1], 0));
+            hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((npix_pad + RB - 1) / RB)), dim3(RB), 0, st, rc, sa, pa, r->d_film);
+            if (lanes == 2) HIPCHK(c, hipEventRecord(r->ev_acc[l], st));
+        }
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipEventRecord(r->ev_pool[ev_class.size()], c->stream));
-        HIPCHK(c, hipMemcpyAsync(hcounts.data(), pa.counts, hcounts.size() * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (size_t e = 0; e < ev_class.size(); ++e) {
-            float ems = 0.f;
-            HIPCHK(c, hipEventElapsedTime(&ems, r->ev_pool[e], r->ev_pool[e + 1]));
-            r->stats.ms_by_kernel[ev_class[e]] += ems;
-            r->stats.launches_by_kernel[ev_class[e]] += 1;
-        }
-        r->stats.passes++;
-        r->stats.samples += (uint64_t)W * H * rc.s_count;
-        // closest rays: every live path in the queue of bounce b (padded slots are not live)
-        const uint64_t pad = (uint64_t)(npix_pad - (size_t)W * H) * rc.s_count;
-        for (int b = 0; b <= p->max_depth; ++b) {
-            r->q_closest[b] += hcounts[(size_t)b * PM_CNT_STRIDE] - (b == 0 ? pad : 0);
-            r->q_shadow[b] += hcounts[(size_t)(nb + b) * PM_CNT_STRIDE];
-        }
-        for (int b = 0; b <= p->max_depth; ++b) r->stats.closest_rays += hcounts[(size_t)b * PM_CNT_STRIDE] - (b == 0 ? pad : 0);
-        for (int b = 0; b < nb; ++b) r->stats.shadow_rays += hcounts[(size_t)(nb + b) * PM_CNT_STRIDE];
+        HIPCHK(c, hipEventRecord(r->ev_pool[l][ev_class.size()], st));
+        HIPCHK(c, hipMemcpyAsync(r->h_counts[l], pa.counts, cnt_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        lr.busy = true;
+        if (lanes == 1 && (rcode = harvest(0))) return rcode;
+    }
+    if ((rcode = harvest(0)) || (rcode = harvest(1))) return rcode;
+    if (lanes == 2 && pass_index > 1) {      // the context's stream - and every later call on it - comes after lane 1's work
+        HIPCHK(c, hipEventRecord(r->ev_join, r->stream1));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, r->ev_join, 0));
     }
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1684,6 +1765,7 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     }
     if (debug_one) {
         float4 h[3]; float fwv;
+        const PathArrays& pa = r->pb[0].pa;
         HIPCHK(c, hipMemcpy(&h[0], pa.L, 16, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(&h[1], pa.lambda_s, 16, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(&h[2], pa.pdf, 16, hipMemcpyDeviceToHost));

@@ -94,6 +94,7 @@ def test_c4_full_size(pm, ora, monkeypatch):
     again = agg.intersect(r3)
     assert ((again["prim_id"] == MISS) | (again["t"] < gpu["t"][hit])).all()
     # ---- render: two passes == one pass; a row band == the rows of the whole image
+    monkeypatch.setenv("PBRT_MI355_LANES", "1")
     st1 = integ.render()
     one = integ.film().copy()
     assert st1["passes"] == 1 and st1["samples"] == res[0] * res[1] * 2
@@ -104,6 +105,12 @@ def test_c4_full_size(pm, ora, monkeypatch):
     assert st2["passes"] == 2
     assert np.array_equal(integ.film().view(np.uint64), one.view(np.uint64)), "the film depends on how the samples are cut into passes"
     assert st2["fallback_walks"] == 0
+    # the default at this size: two lanes (two streams, one sample index each)
+    monkeypatch.delenv("PBRT_MI355_LANES")
+    integ.clear()
+    st3 = integ.render()
+    assert st3["passes"] == 2 and st3["closest_rays"] == st1["closest_rays"] and st3["shadow_rays"] == st1["shadow_rays"]
+    assert np.array_equal(integ.film().view(np.uint64), one.view(np.uint64)), "the film depends on the lanes"
     band = (0, 1048, res[0], 1112)
     integ.clear()
     integ.render(window=band)
