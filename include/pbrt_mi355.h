@@ -270,7 +270,10 @@ int pm_set_film(pm_ctx* ctx, const PmFilm* film, uint32_t struct_bytes /* sizeof
 /* Integrate::render() restricted to a pixel/sample window; accumulates into the film in sample-index order.
  * The window is rendered in passes of at most 2^26 paths (about 200 bytes of device memory per path, allocated on first
  * use and kept; never more than half of what is free on the device; PBRT_MI355_PASS_PATHS lowers it).  The film does not
- * depend on how the window is cut into passes. */
+ * depend on how the window is cut into passes.  A call of at least 2^22 paths and two sample indices runs its passes
+ * alternately on two streams of the library's own (same memory: the passes are half as large; PBRT_MI355_LANES=1 keeps one
+ * stream): the call is blocking all the same, the film and every statistic but the per-class times - which then overlap - are
+ * bit-identical, and PmRenderStats.passes counts the halves. */
 int pm_render(pm_ctx* ctx, const PmRenderParams* params, uint32_t struct_bytes /* sizeof(PmRenderParams) */);
 int pm_film_clear(pm_ctx* ctx);
 /* RGBPixel{rgb_sum[3], weight_sum} as 4 doubles per pixel, row-major over pixel_bounds; host or device pointer */
