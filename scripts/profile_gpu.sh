@@ -8,8 +8,13 @@ OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd $R
 step() { echo "== $*" >> $OUT/progress.log; }
+# C2 twice: on ONE lane (PBRT_MI355_LANES=1: every kernel alone on the chip - the durations bench.py's roofline.kernel_ms must
+# agree with; bench.py measures its roofline in such steps), then as the default runs it (two lanes: kernels of two passes overlap)
 step stats-path
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_path -o path --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/stats_path.log 2>&1 || exit 1
+PBRT_MI355_LANES=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_path -o path --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/stats_path.log 2>&1 || exit 1
+step stats-path-two-lanes
+PBRT_MI355_LANES=2 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_path2 -o path2 --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/stats_path2.log 2>&1 || exit 1
+[ "${PROFILE_STATS_ONLY_PATH:-0}" = 1 ] || {
 step stats-trace
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_trace -o trace --output-format csv -- python3 bench.py --workload trace --steps 5 --warmup 1 --no-cpu-baseline > $OUT/stats_trace.log 2>&1 || exit 1
 step stats-c4
@@ -18,6 +23,8 @@ step stats-patch
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_patch -o patch --output-format csv -- python3 bench.py --workload patch --steps 5 --warmup 1 --no-cpu-baseline > $OUT/stats_patch.log 2>&1 || exit 1
 step stats-c5
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats_c5 -o c5 --output-format csv -- python3 bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/stats_c5.log 2>&1 || exit 1
+}
+export PBRT_MI355_LANES=1      # the counter passes: one lane (rocprofv3 serialises the dispatches anyway)
 for W in ${PROFILE_WORKLOADS:-path trace patch c4 c5}; do
   case $W in
     path) ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-secondary";;
@@ -36,6 +43,7 @@ for W in ${PROFILE_WORKLOADS:-path trace patch c4 c5}; do
   timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_lanes_$W -o l --output-format csv -- python3 bench.py $ARGS > $OUT/pmc_lanes_$W.log 2>&1 || exit 1
 done
 # lanes of the C4 closest-hit walk with the queue sorted per bounce (compare pmc_lanes_c4)
+[ "${PROFILE_REORDER:-1}" = 1 ] || { step done; exit 0; }
 step pmc-lanes-c4-reorder
 PBRT_MI355_REORDER=5 timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_lanes_c4_reorder -o l --output-format csv -- python3 bench.py --workload c4 --spp 8 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_lanes_c4_reorder.log 2>&1 || exit 1
 step done
