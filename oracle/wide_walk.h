@@ -286,6 +286,10 @@ struct WideWalker {
                 if (ctr) ctr->prims_tested++;
                 const float* f = reinterpret_cast<const float*>(prims + (size_t)unit * 16);
                 if (sphere_prefilter(ro, rd, R, D, f, f[12], f[18], f[19], tcs)) defer_prim(unit);
+                else {      // the counting kernels' confirm path (pm_device.hpp trace_flat): the interval test all the same (not counted)
+                    uint32_t id; float t, u, v;
+                    if (test_prim(0, unit, ro, rd, ray_tmax, &id, &t, &u, &v)) t_rej = rmin(t_rej, t);
+                }
             }
             if (!any_hit) {
                 auto rcp = [D](float d) { return std::fabs(d) < 1e-18f * D ? std::copysign(1e18f / D, d) : 1.0f / d; };   // pm_device.hpp safe_rcp_dir
@@ -314,7 +318,7 @@ struct WideWalker {
                 if (any_hit && found) break;
                 (void)test_now(2, cu.unit);
             }
-            const bool false_reject = !any_hit && t_rej < (found ? *ht : ray_tmax);
+            const bool false_reject = any_hit ? (!found && t_rej < std::numeric_limits<float>::infinity()) : t_rej < (found ? *ht : ray_tmax);
             if ((sure && !(found && (any_hit || *ht <= tconf))) || false_reject) { slow = true; if (ctr) ctr->fallback_walks++; }
         }
         if (slow) {             // second pass, slow entry: everything again, exactly
@@ -358,6 +362,7 @@ struct WideWalker {
         bool exact_mode = false;
         for (int attempt = 0; attempt < 2; ++attempt) {
             float t_max = ray_tmax, tcull = ray_tmax;
+            float t_rej = std::numeric_limits<float>::infinity();      // confirm path of the sphere pre-filter (counting kernels)
             bool sure = false;
             std::vector<std::pair<uint32_t, float>> cand;   // (record unit, lower bound of t: 0 unless a certain hit)
             std::vector<uint32_t> deferred;     // spheres that passed the pre-filter: exact tests after everything else
@@ -426,7 +431,11 @@ struct WideWalker {
                         bool immediate = true;
                         if (type == 0 && !exact_mode && defer_spheres) {
                             const float* f = reinterpret_cast<const float*>(prims + (size_t)unit * 16);
-                            if (!sphere_prefilter(ro, rd, R, D, f, f[12], f[18], f[19], tcull)) immediate = false;
+                            if (!sphere_prefilter(ro, rd, R, D, f, f[12], f[18], f[19], tcull)) {
+                                immediate = false;      // the counting kernels' confirm path: the interval test all the same (not counted)
+                                uint32_t id; float t, u, v;
+                                if (test_prim(0, unit, ro, rd, ray_tmax, &id, &t, &u, &v)) t_rej = rmin(t_rej, t);
+                            }
                             else if (deferred.size() < 2) { deferred.push_back(unit); immediate = false; }
                         }
                         if (type == 2 && !exact_mode) {
@@ -462,7 +471,8 @@ struct WideWalker {
                 if (ctr) ctr->exact_tests++;
                 (void)tri_take(cu.first);
             }
-            bool confirmed = !sure || (found && (any_hit || *ht <= tcull));
+            const bool false_reject = any_hit ? (!found && t_rej < std::numeric_limits<float>::infinity()) : t_rej < (found ? *ht : ray_tmax);
+            bool confirmed = (!sure || (found && (any_hit || *ht <= tcull))) && !false_reject;
             if (confirmed || exact_mode) {
                 for (uint32_t unit : deferred) {        // the kernel's second pass (sphere_fix)
                     if (any_hit && found) break;

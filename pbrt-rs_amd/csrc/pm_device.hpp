@@ -603,6 +603,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
     uint32_t oct = 0;
     float R = 0.f, D = 0.f, tmax = 0.f, tcull = 0.f;
     bool found = false, exact_mode = false;
+    float t_rej = INFINITY;    // (counting kernels) nearest hit of a sphere the pre-filter rejected: the confirm path, see trace_flat
     // "a certain triangle hit was claimed": closest-hit walks do not track it - such a claim always lowers tcull below
     // ray.tmax (and when an exact sphere / patch hit lowered it instead, the confirmation below holds trivially); measured
     // +6 % on C3.  Any-hit walks test it at every step, so they keep the flag (measured).
@@ -625,7 +626,7 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
     uint2 spill[PM_SPILL_STACK];
 
     auto start_walk = [&]() {
-        tmax = ray.tmax; tcull = ray.tmax; sure_any = false; found = false; qn = 0; sp = 0; steps = 0; np = 0; ph = 0;
+        tmax = ray.tmax; tcull = ray.tmax; sure_any = false; found = false; qn = 0; sp = 0; steps = 0; np = 0; ph = 0; t_rej = INFINITY;
         sph0 = 0xFFFFFFFFu; sph1 = 0xFFFFFFFFu;
         hit.prim_id = 0xFFFFFFFFu; hit.t = ray.tmax; hit.u = 0.0f; hit.v = 0.0f;
         cur = make_uint2(0u, (1u << 8) | perm8(1u, oct));     // pseudo group holding only the root
@@ -801,7 +802,8 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                 }
                 finished = false;
                 // did the exact tests confirm what culling assumed?
-                const bool confirmed = !PM_SURE || (found && (ANY || hit.t <= tcull));
+                const bool false_reject = COUNT && MIXED && (ANY ? (!found && t_rej < INFINITY) : t_rej < (found ? hit.t : ray.tmax));
+                const bool confirmed = (!PM_SURE || (found && (ANY || hit.t <= tcull))) && !false_reject;
                 if (confirmed || exact_mode) {
                     // closest hit: commit what the walk found, sphere_fix improves it; any hit: an occluded ray needs no
                     // sphere test, an unoccluded one is committed by sphere_fix
@@ -939,8 +941,13 @@ PMD void trace_persistent(const PmWideNode* __restrict__ nodes, const uint4* __r
                             m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
                             const float radius = __uint_as_float(r3.x);
                             if (!exact_mode) {
-                                if (!sphere_prefilter(ray.o, ray.d, R, D, m, radius, __uint_as_float(r4.z), __uint_as_float(r4.w), tcull))
+                                if (!sphere_prefilter(ray.o, ray.d, R, D, m, radius, __uint_as_float(r4.z), __uint_as_float(r4.w), tcull)) {
+                                    if (COUNT) {        // confirm path (see trace_flat): the interval test all the same
+                                        float st, su, sv; uint32_t sid;
+                                        if (sphere_test_cold(r, ray.o, ray.d, ray.tmax, &st, &su, &sv, &sid)) t_rej = fminf(t_rej, st);
+                                    }
                                     continue;
+                                }
                                 const uint32_t unit = pbase + (off + j) * PM_UNITS_SPHERE;
                                 if (sph0 == 0xFFFFFFFFu) { sph0 = unit; continue; }
                                 if (sph1 == 0xFFFFFFFFu) { sph1 = unit; continue; }
@@ -1167,6 +1174,12 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
         // triangles: a certain triangle hit bounds the distance within which a sphere or a patch still matters (any hit: the ray
         // is decided and skips them altogether) - tested first, against the ray's own t_max, twice as many were deferred.
         const float tcs = (cull.cn / cull.cd) * 1.00001f;
+        // CONFIRM PATH of the sphere and patch pre-filters (counting kernels, i.e. every test that compares counters): a primitive
+        // a pre-filter rejects is put through its reference arithmetic all the same, and should that hit lie in front of what the
+        // ray ends up with (any hit: should there be one although the ray ends up unoccluded), the ray is counted in `fallback`
+        // and redone exactly by the second pass.  So a false reject can neither pass a counting run unnoticed nor falsify its
+        // result; the timed kernels skip the check.
+        float t_rej = INFINITY;
         for (uint32_t i = 0; i < fs.n_sphere; ++i) {
             const uint32_t unit = as_uniform(fs.units)[i];
             if (live && !slow && !(ANY && (found || sure))) {
@@ -1179,16 +1192,17 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
                 m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
                 if (sphere_prefilter(ray.o, ray.d, R, D, m, __uint_as_float(r3.x), __uint_as_float(r4.z), __uint_as_float(r4.w), tcs))
                     defer_prim(unit);
+                else if (COUNT) {       // confirm path, as for the patches below: the interval test all the same (not counted in
+                                        // `exact`, which stays the number of interval tests the timed kernels run)
+                    float st, su, sv; uint32_t sid;
+                    if (sphere_test_cold(prims + unit, ray.o, ray.d, ray.tmax, &st, &su, &sv, &sid)) t_rej = fminf(t_rej, st);
+                }
             }
         }
-        // CONFIRM PATH of the patch pre-filter (counting kernels, i.e. every test that compares counters): a patch the pre-filter
-        // rejects is put through the reference arithmetic all the same, and should that hit lie in front of what the ray ends up
-        // with, the ray is counted in `fallback` and redone exactly by the second pass.  So a false reject can neither pass a
-        // counting run unnoticed nor falsify its result; the timed kernels skip the check.  (Why none is expected: the reference
-        // only runs its patch test for rays that pass ITS slab test of the same corner box - the leaf bounds of its BVH,
-        // bilinear_patch.rs:176-181, bounds.rs:381-404, widened by 1 + 2 gamma(3) ~ 4e-7 - and patch_prefilter pads that box by
-        // 1e-4 of the coordinates and compares with a relative slack of 1e-4: it accepts a superset.)
-        float t_rej = INFINITY;
+        // (Why no false reject of a PATCH is expected: the reference only runs its patch test for rays that pass ITS slab test of
+        // the same corner box - the leaf bounds of its BVH, bilinear_patch.rs:176-181, bounds.rs:381-404, widened by
+        // 1 + 2 gamma(3) ~ 4e-7 - and patch_prefilter pads that box by 1e-4 of the coordinates and compares with a relative slack
+        // of 1e-4: it accepts a superset.  Spheres: the forward error bounds of sphere_prefilter.)
         if (PATCH && !ANY) {        // (round 1 ran the reference arithmetic at once, for every ray and every patch: ~300 instructions each)
             const f3 pinv = mk3(safe_rcp_dir(ray.d.x, D), safe_rcp_dir(ray.d.y, D), safe_rcp_dir(ray.d.z, D));
             for (uint32_t i = 0; i < fs.n_patch; ++i) {
@@ -1242,7 +1256,7 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
             }
         }
         // ---- did the exact tests confirm what culling assumed?  If not the ray is slow too (counted; never seen)
-        const bool false_reject = COUNT && PATCH && !ANY && live && !slow && t_rej < (found ? hit.t : ray.tmax);
+        const bool false_reject = COUNT && live && !slow && (ANY ? (!found && t_rej < INFINITY) : t_rej < (found ? hit.t : ray.tmax));
         const bool unconfirmed = (live && !slow && sure && !(found && (ANY || hit.t <= tconf))) || false_reject;
         if (COUNT && unconfirmed) ctr->fallback++;
         // ---- commit.  Closest hit: what the triangles gave is committed now and the second pass improves it with the

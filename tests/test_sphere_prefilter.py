@@ -138,3 +138,38 @@ def test_disjoint_spheres_bit_exact(pm, ora):
     for f in ("prim_id", "t", "u", "v"):
         assert np.array_equal(wide[f].view(np.uint32), ref[f].view(np.uint32)), f
     assert wc["exact_tests"] < 0.8 * wc["prims_tested"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flat_max", ["64", "0"])
+@pytest.mark.parametrize("seed,spread,partial", [(2, 3.0, True), (3, 300.0, True)])
+def test_sphere_prefilter_confirm_path_on_the_gpu(pm, ora, monkeypatch, seed, spread, partial, flat_max):
+    """Round 3: the counting kernels put every sphere their pre-filter rejects through the interval test all the same (the confirm
+    path, as for patches); a rejected sphere that would have been the hit counts as a fallback and the ray is redone exactly.
+    On the hard rays of the CPU test: no fallback, counters equal to the mirror's, hits equal to the timed kernels'."""
+    monkeypatch.setenv("PBRT_MI355_FLAT_MAX", flat_max)
+    rng = np.random.default_rng(seed)
+    prims, centres, radii = _spheres(pm, rng, 24, spread, partial)
+    pos = np.array([[-4, -4, -2], [4, -4, -2], [4, 4, -2], [-4, 4, -2]], np.float32) * np.float32(max(1.0, spread / 3))
+    prims.append(pm.TriangleMesh(pos, [[0, 1, 2], [0, 2, 3]]))
+    agg = pm.GpuAggregate(prims)
+    is_flat = agg.info.flat_prims != 0
+    assert is_flat == (flat_max != "0")
+    rays = _rays(pm, rng, centres, radii, 200_000)
+    timed, timed_occ = agg.intersect(rays), agg.intersect_p(rays)
+    agg.set_counting(True)
+    for any_hit in (False, True):
+        agg.reset_counters()
+        got = agg.intersect_p(rays) if any_hit else agg.intersect(rays)
+        c = agg.counters()
+        cpu, cw = ora.wide_trace(agg.node_buffer(), agg.prim_buffer(), rays, any_hit=any_hit, flat=is_flat)
+        for k in ("nodes_visited", "prims_tested", "exact_tests", "fallback_walks"):
+            assert c[k] == cw[k], (any_hit, k, c, cw)
+        assert c["fallback_walks"] == 0
+        if any_hit:
+            assert np.array_equal(got.astype(bool), timed_occ.astype(bool)) and np.array_equal(got.astype(bool), cpu.astype(bool))
+        else:
+            for f in ("prim_id", "t", "u", "v"):
+                assert np.array_equal(got[f].view(np.uint32), timed[f].view(np.uint32)), f
+            assert np.array_equal(got["t"].view(np.uint32), cpu["t"].view(np.uint32))
+    agg.set_counting(False)
