@@ -1584,6 +1584,9 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     struct LaneRun { bool busy = false; std::vector<int> ev_class; int s_count = 0; };
     LaneRun run[2];
     hipStream_t streams[2] = {c->stream, r->stream1};
+    // whatever way this function is left (an error return in the middle of a frame included), nothing of it is still running on
+    // either lane afterwards: the call is blocking, and the next call reuses the lanes' buffers
+    struct Drain { hipStream_t a, b; ~Drain() { if (b) (void)hipStreamSynchronize(b); (void)hipStreamSynchronize(a); } } drain{c->stream, lanes == 2 ? r->stream1 : nullptr};
     uint32_t* works[2] = {c->d_work, r->d_work1};
     uint4* defers[2] = {c->d_defer, r->d_defer1};
     uint32_t* slows[2] = {c->d_slow, r->d_slow1};
