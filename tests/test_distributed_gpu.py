@@ -52,9 +52,13 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.parametrize("world", [2, 4])
-def test_ranks_on_one_gpu_split_and_merge(tmp_path, world):
-    """2 and 4 ranks sharing the one card (RES = 72 x 40: five 8-row units over four ranks = ragged row bands 16 / 8 / 8 / 8)"""
+def test_ranks_on_one_gpu_split_and_merge(tmp_path, world, monkeypatch):
+    """2 and 4 ranks sharing the one card (RES = 72 x 40: five 8-row units over four ranks = ragged row bands 16 / 8 / 8 / 8).
+    The four-rank case renders on two lanes per rank (eight streams on the card); the single-process reference on one."""
+    if world == 4:
+        monkeypatch.setenv("PBRT_MI355_LANES", "2")       # (inherited by the spawned ranks)
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    monkeypatch.setenv("PBRT_MI355_LANES", "1")
     pm, integ = _integrator()
     integ.render()
     whole = integ.film()
