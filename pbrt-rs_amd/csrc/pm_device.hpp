@@ -1066,7 +1066,20 @@ PMD cuint_p as_uniform(const uint32_t* p) { return (cuint_p)p; }
 #define PM_DEFER_PATCH 0x40000000u      /* deferred unit is a patch record (otherwise a sphere record) */
 #define PM_DEFER_NONE 0xFFFFFFFFu
 
-template <bool ANY, bool COUNT, bool PATCH, class FetchFn, class CommitFn>
+// COH (closest hit, timed kernels; round 3): the caller knows that a wave's 64 work items are COHERENT rays - the camera rays of an
+// 8 x 8 pixel tile, bounce 0 of a pass.  When they also share one origin (a pinhole camera; checked per wave) the wave first asks,
+// one lane per table entry, "can ANY ray of this tile reach triangle i?" and sweeps only the entries that say yes - 2 to 6 of the
+// 36 of the C2 box.  The test is perspective projection from the common origin: with all three vertices in front of the origin
+// (inside the cone of 84 degrees around the tile's first direction, so the divisions are well conditioned) a ray that meets the
+// triangle has its projected direction inside the bounding box of the projected vertices; the tile's own bounding box of
+// projected directions is padded by 1e-4 of its size + 2e-5 absolute (rounding of either side is ~2e-6).  Anything else - a
+// vertex outside the cone, rays that do not share their origin or spread beyond 60 degrees - keeps the entry.  Culled entries are
+// entries the exact test rejects for every ray of the wave, so hits are unchanged bit for bit (the queues may hold fewer useless
+// candidates); the counting kernels, whose counters are the CPU mirror's, never cull.
+PMD float wave_min64(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
+PMD float wave_max64(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+
+template <bool ANY, bool COUNT, bool PATCH, bool COH = false, class FetchFn, class CommitFn>
 PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_items, uint32_t* cand, int stride,
                     uint4* __restrict__ defer_list, uint32_t* __restrict__ defer_count, uint32_t* __restrict__ slow_list,
                     uint32_t* __restrict__ slow_count, uint32_t defer_cap, TravCounters* ctr, FetchFn fetch, CommitFn commit) {
@@ -1130,6 +1143,77 @@ PMD void trace_flat(FlatScene fs, const uint4* __restrict__ prims, uint32_t n_it
         // counting build only ever turns off)
         FlatShared shared; shared.sv = mk3(0.f, 0.f, 0.f); shared.m = mk3(0.f, 0.f, 0.f); shared.e2m = 0.f;
         shared.sg = 1.0f; shared.det = 0.f; shared.tt = 0.f;
+        if constexpr (COH && !COUNT && !ANY) {
+            // ---- which entries can the rays of this wave reach at all?  (see the comment above trace_flat)
+            unsigned long long emask = fs.n_tri >= 64u ? ~0ull : ((1ull << fs.n_tri) - 1ull);
+            const unsigned long long lv = __ballot(live);
+            if (lv != 0ull) {
+                const int src = __ffsll((long long)lv) - 1;
+                const f3 o0 = mk3(__shfl(ray.o.x, src), __shfl(ray.o.y, src), __shfl(ray.o.z, src));
+                const f3 c = mk3(__shfl(ray.d.x, src), __shfl(ray.d.y, src), __shfl(ray.d.z, src));
+                const f3 ac = abs3(c);
+                const f3 ax = (ac.x <= ac.y && ac.x <= ac.z) ? mk3(1.f, 0.f, 0.f) : (ac.y <= ac.z ? mk3(0.f, 1.f, 0.f) : mk3(0.f, 0.f, 1.f));
+                const f3 ex = fcross(c, ax), ey = fcross(c, ex);
+                const float cc = fdot(c, c), w = fdot(ray.d, c);
+                const bool same = __float_as_uint(ray.o.x) == __float_as_uint(o0.x) && __float_as_uint(ray.o.y) == __float_as_uint(o0.y) &&
+                                  __float_as_uint(ray.o.z) == __float_as_uint(o0.z);
+                const bool ok = !live || (same && w > 0.0f && w * w > 0.25f * (cc * fdot(ray.d, ray.d)));
+                if (__all(ok) && cc > 0.0f && cc < INFINITY) {
+                    const float sx = live ? fdot(ray.d, ex) / w : 0.0f, sy = live ? fdot(ray.d, ey) / w : 0.0f;
+                    const float x0 = wave_min64(live ? sx : INFINITY), x1 = wave_max64(live ? sx : -INFINITY);
+                    const float y0 = wave_min64(live ? sy : INFINITY), y1 = wave_max64(live ? sy : -INFINITY);
+                    const float px = __fmaf_rn(1e-4f, x1 - x0, 2e-5f * (1.0f + fmaxf(fabsf(x0), fabsf(x1))));
+                    const float py = __fmaf_rn(1e-4f, y1 - y0, 2e-5f * (1.0f + fmaxf(fabsf(y0), fabsf(y1))));
+                    bool keep = lane < fs.n_tri;
+                    if (keep) {
+                        const uint4* r = prims + (fs.tris[lane].unit & PM_FLAT_UNIT_MASK);
+                        const uint4 r0 = r[0], r1 = r[1], r2 = r[2];
+                        const f3 a0 = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)) - o0;
+                        const f3 a1 = mk3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y)) - o0;
+                        const f3 a2 = mk3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x)) - o0;
+                        const float w0 = fdot(a0, c), w1 = fdot(a1, c), w2 = fdot(a2, c);
+                        // in front, and within ~84 degrees of the axis: w_k > 0.1 |a_k| |c|
+                        const bool front = w0 > 0.0f && w1 > 0.0f && w2 > 0.0f && w0 * w0 > 0.01f * (cc * fdot(a0, a0)) &&
+                                           w1 * w1 > 0.01f * (cc * fdot(a1, a1)) && w2 * w2 > 0.01f * (cc * fdot(a2, a2));
+                        if (front) {
+                            const float u0 = fdot(a0, ex) / w0, u1 = fdot(a1, ex) / w1, u2 = fdot(a2, ex) / w2;
+                            const float v0 = fdot(a0, ey) / w0, v1 = fdot(a1, ey) / w1, v2 = fdot(a2, ey) / w2;
+                            const float ulo = fminf(u0, fminf(u1, u2)), uhi = fmaxf(u0, fmaxf(u1, u2));
+                            const float vlo = fminf(v0, fminf(v1, v2)), vhi = fmaxf(v0, fmaxf(v1, v2));
+                            // (written so that a NaN keeps the entry)
+                            const bool out = ulo > x1 + px || uhi < x0 - px || vlo > y1 + py || vhi < y0 - py;
+                            keep = !out;
+                        }
+                    }
+                    emask = __ballot(keep);
+                }
+            }
+            uint32_t prev = 0xFFFFFFF0u;
+            for (unsigned long long m = emask; m != 0ull; m &= m - 1ull) {
+                const uint32_t i = (uint32_t)__ffsll((long long)m) - 1u;
+                const cuint4_p e = as_uniform(reinterpret_cast<const uint4*>(fs.tris + i));
+                const uint4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3];
+                // the chained forms need the entry before this one to have been swept
+                const uint32_t flags = (i == prev + 1u) ? q1.w : (q1.w & PM_FLAT_UNIT_MASK);
+                prev = i;
+                FlatTerms ft;
+                if (!tri_reject_flat(ray.o, ray.d, KD, R2,
+                                     mk3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)),
+                                     mk3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)),
+                                     mk3(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z)),
+                                     mk3(__uint_as_float(q3.x), __uint_as_float(q3.y), __uint_as_float(q3.z)),
+                                     __uint_as_float(q0.w), __uint_as_float(q2.w), __uint_as_float(q3.w), flags, &shared, cull, &ft)) {
+                    float ln, ld;
+                    (void)tri_certain_flat(ft, __uint_as_float(q2.w), epsb_ray, &cull, true, &ln, &ld);
+                    if (qn < PM_FLAT_CAND_MAX) {
+                        cand[qn * stride] = q1.w & PM_FLAT_UNIT_MASK;
+                        cand[(PM_FLAT_CAND_MAX + qn) * stride] = __float_as_uint(ln);
+                        cand[(2 * PM_FLAT_CAND_MAX + qn) * stride] = __float_as_uint(ld);
+                        ++qn;
+                    } else slow = true;
+                }
+            }
+        } else
         for (uint32_t i0 = 0; i0 < fs.n_tri; i0 += kChunk) {
         if (ANY) {
             sure = !(cull.cn == tcull && cull.cd == 1.0f);

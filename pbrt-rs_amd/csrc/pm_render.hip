@@ -219,7 +219,7 @@ __global__ __launch_bounds__(TB) PM_TRAV_ATTR(true, KIND) void shadow_kernel(Sce
     if (tc.overflow) atomicAdd(&counters[3], 1ull);
 }
 // flat-sweep variants for scenes of at most PM_FLAT_MAX_PRIMS primitives (pm_device.hpp trace_flat)
-template <bool COUNT, bool PATCH>
+template <bool COUNT, bool PATCH, bool COH = false>
 __global__ __launch_bounds__(TB) PM_FLAT_ATTR void closest_flat_kernel(PmFlatScene fs, SceneArrays sc, PathArrays pa, uint32_t g,
                                                           const uint32_t* __restrict__ count, uint4* __restrict__ defer_list, uint32_t defer_cap,
                                                           uint32_t* __restrict__ defer_count, uint32_t* __restrict__ slow_list,
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(TB) PM_FLAT_ATTR void closest_flat_kernel(PmFlatSce
     auto commit = [&](uint32_t i, bool found, const HitRec& h) {
         pa.hit[i] = make_float4(__uint_as_float(h.prim_id), h.t, h.u, h.v);
     };
-    trace_flat<false, COUNT, PATCH>(fs, sc.prims, *count, cand + threadIdx.x, TB, defer_list, defer_count, slow_list,
+    trace_flat<false, COUNT, PATCH, COH>(fs, sc.prims, *count, cand + threadIdx.x, TB, defer_list, defer_count, slow_list,
                              defer_count + PM_WORK_SLOTS, defer_cap, &tc, fetch, commit);
     if (COUNT) {
         atomicAdd(&counters[2], (unsigned long long)tc.prims); atomicAdd(&counters[6], (unsigned long long)tc.exact);
@@ -1577,6 +1577,8 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
     // different phases of a bounce from the start: a sweep beside a shade kernel, not two of a kind); (ii) the film is added
     // to in sample-index order: the accumulate launch of pass k waits for that of pass k - 1 (ev_acc); (iii) a lane's buffers
     // are reused by its next pass, which the host issues once it has collected the counts of the previous one.
+    bool coh_on = true;
+    if (const char* e = std::getenv("PBRT_MI355_COH")) coh_on = std::atoi(e) != 0;
     int stagger = 2, grid_div = 1;
     if (const char* e = std::getenv("PBRT_MI355_STAGGER")) { int v = std::atoi(e); if (v >= 0 && v <= 64) stagger = v; }
     if (const char* e = std::getenv("PBRT_MI355_LANE_GRID_DIV")) { int v = std::atoi(e); if (v >= 1 && v <= 4) grid_div = v; }
@@ -1672,8 +1674,12 @@ static int render_impl(pm_ctx* c, const PmRenderParams* p, bool debug_one, int d
                 }
             }
             if (flat) {
+                // bounce 0: the queue is the identity (entry i = slot i = pixel-in-tile x sample), so a wave holds the camera rays of
+                // one 8 x 8 tile: the COH instantiation culls the table per wave (pm_device.hpp trace_flat; PBRT_MI355_COH=0: off)
+                const bool coh = b == 0 && coh_on;
                 auto kernel = c->counting ? (fpatch ? closest_flat_kernel<true, true> : closest_flat_kernel<true, false>)
-                                          : (fpatch ? closest_flat_kernel<false, true> : closest_flat_kernel<false, false>);
+                                          : coh ? (fpatch ? closest_flat_kernel<false, true, true> : closest_flat_kernel<false, false, true>)
+                                                : (fpatch ? closest_flat_kernel<false, true> : closest_flat_kernel<false, false>);
                 hipLaunchKernelGGL(kernel, gf, dim3(TB), 0, st, c->flat, sa, pa, gen, cnt_in, d_defer, defer_cap, d_work + PM_WORK_SLOTS + wslot, d_slow, c->d_counters);
             } else {
                 auto kernel = c->counting ? (kind == PM_WALK_MIXED ? closest_kernel<true, PM_WALK_MIXED> : kind == PM_WALK_PATCH ? closest_kernel<true, PM_WALK_PATCH> : closest_kernel<true, PM_WALK_TRI>)
