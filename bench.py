@@ -54,7 +54,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 L3_BYTES = 256e6        # Infinity Cache: a scene below this stays on-die between launches
 KERNEL_NAMES = ["raygen_kernel", "closest_kernel", "shade_kernel", "shadow_kernel", "accumulate_kernel"]
 # timed (non-counting) variants as rocprofv3 names them
-PMC_NAME = {"raygen_kernel": r"^raygen_kernel", "closest_kernel": r"^closest(_flat)?_kernel<false", "shade_kernel": r"^shade_kernel",
+# (closest_flat_kernel<false, PATCH, true> is the camera-ray instantiation, one launch in six: the class is priced by the other)
+PMC_NAME = {"raygen_kernel": r"^raygen_kernel", "closest_kernel": r"^closest(_flat)?_kernel<false(?!.*, true>$)", "shade_kernel": r"^shade_kernel",
             "shadow_kernel": r"^shadow(_flat)?_kernel<false", "accumulate_kernel": r"^accumulate_kernel"}
 
 
