@@ -126,6 +126,7 @@ def test_film_independent_of_pass_size(pm, monkeypatch):
     sample-index order, film.rs add_sample) and the ray counts must not depend on where the cuts fall."""
     sd = pm.scenes.cornell_scene((64, 64))
     films = []
+    monkeypatch.setenv("PBRT_MI355_LANES", "1")      # (two lanes halve the passes: tests/test_lanes_gpu.py)
     for paths in (None, "4096", "12288"):       # one pass; one sample per pass; three samples per pass (8 = 3 + 3 + 2)
         if paths is None:
             monkeypatch.delenv("PBRT_MI355_PASS_PATHS", raising=False)
